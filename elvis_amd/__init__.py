@@ -1,0 +1,17 @@
+"""elvis_amd - MI355X-native implementation of ELVIS's client-side restoration hot path.
+
+Drop-in for the reference's `elvis.py` / `utils.py` call surface: the names
+below keep the reference's spelling, argument meaning and error behaviour; the arithmetic runs
+as hand-written HIP (gfx950) kernels in `elvis_amd/lib/libelvis_amd.so` behind the C ABI of
+`include/elvis_amd.h`.  There is no CPU fallback: without a ROCm GPU (or without the built
+library) the restoration entry points raise RuntimeError.
+"""
+from .sharding import (ChunkSpec, chunk_for_devices, parallel_process_frames, rank_frame_range,  # noqa: F401
+                       resolve_device_list, _resolve_device_list)
+from .recompose import (combine_blocks_into_image, split_image_into_blocks,  # noqa: F401
+                        restore_video_adaptively)
+from .tiler import adaptive_restore, blended_restoration, resource_aware_restore  # noqa: F401
+from .restore import (get_sinsr_model, get_sinsr_upsample_fn, restore_frames_rounds,  # noqa: F401
+                      restore_frames_sinsr, restore_with_sinsr_naive)
+
+__version__ = "0.1.0"

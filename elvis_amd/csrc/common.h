@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of libelvis_amd.  CDNA4 only: 64-wide waves,
+// no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/elvis_amd.h"
+
+#define ELVIS_WAVE 64
+
+void elvis_set_error(const char* fmt, ...);
+
+#define ELVIS_REQUIRE(cond, ...)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            elvis_set_error(__VA_ARGS__);             \
+            return ELVIS_E_INVALID;                   \
+        }                                             \
+    } while (0)
+
+#define ELVIS_CHECK_LAUNCH(name)                                              \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            elvis_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return ELVIS_E_RUNTIME;                                           \
+        }                                                                     \
+    } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int code = ELVIS_F32;
+    static constexpr int VEC = 4;  // elements per 16 bytes
+};
+template <> struct DT<half_t> {
+    static constexpr int code = ELVIS_F16;
+    static constexpr int VEC = 8;
+};
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(half_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ half_t from_f<half_t>(float v) { return (half_t)v; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,419 @@
+// Implicit-GEMM convolution (3x3 / 1x1, stride 1/2, optional fused nearest-2x upsample of the
+// input, optional virtual channel-concat of two inputs, optional fused GroupNorm-affine+SiLU
+// prologue, bias / activation / residual epilogue) on the CDNA4 matrix cores.
+//
+//   D[co][px] = sum_{tap,ci} W[tap][ci][co] * X[px + tap][ci]
+//
+// MFMA operand roles: A = weights (rows = output channels), B = activations (cols = pixels), so
+// each lane ends up holding 4 CONSECUTIVE output channels of one pixel -> one 8-byte (f16) or
+// 16-byte (f32) NHWC store per 16x16 sub-tile.
+//
+// Both dtypes use the same LDS image: rows of 64 bytes (32 halfs / 16 floats of K), grouped in
+// 16-row x 64-byte sub-tiles of 1 KiB, XOR-swizzled with byte ^= ((byte>>9)&1)<<5 (the
+// "st_16x32" swizzle of the CDNA4 guide) which makes every ds_read_b128 lane group hit 16
+// distinct 16-byte slots.  One ds_read_b128 per lane feeds
+//   f16: one v_mfma_f32_16x16x32_f16   (lane (r,g) holds k = 8g..8g+7)
+//   f32: four v_mfma_f32_16x16x4_f32   (lane (r,g) holds k = 4g..4g+3; MFMA e uses element e, so
+//        the four instructions together cover the 16 k of the row - the k order is permuted
+//        identically for A and B, which leaves the sum unchanged).
+// f32 mode is exact IEEE fp32 FMA chains (parity mode); f16 mode accumulates in fp32.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const void* x;
+    const void* x2;
+    const void* w;
+    const float* bias;
+    const void* res;
+    const float* pa;
+    const float* pb;
+    void* out;
+    int n, h, w_in;       // input dims (pre-upsample)
+    int cin, cin_pitch, cin2, cin2_pitch;
+    int cout, cout_pitch, res_pitch;
+    int ksize, stride, pad, upsample;
+    int ho, wo;
+    int act, prologue;
+    int nkc;              // K chunks per tap (over cin+cin2, each KC elements)
+    int nkc1;             // chunks that belong to input 1
+    int co_pad;           // padded cout in the packed weights
+    long long M;          // n*ho*wo
+    int n_co_tiles;
+    long long n_px_tiles;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<half_t> { typedef half8 type; };
+template <> struct Frag<float> { typedef float4v type; };
+
+__device__ __forceinline__ void mma_tile(float4v& acc, const half8& a, const half8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_tile(float4v& acc, const float4v& a, const float4v& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ int lds_row_off(int row, int q) {
+    // byte offset of 16-byte chunk q of `row` in the swizzled image
+    int r = row & 15;
+    return (row >> 4) * 1024 + r * 64 + ((q ^ (((r >> 3) & 1) << 1)) << 4);
+}
+
+template <typename T> __device__ __forceinline__ uint4 prologue_apply(uint4 v, const float* pa, const float* pb);
+template <> __device__ __forceinline__ uint4 prologue_apply<float>(uint4 v, const float* pa, const float* pb) {
+    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float t = fmaf(f[i], pa[i], pb[i]);
+        f[i] = t / (1.0f + expf(-t));
+    }
+    return v;
+}
+template <> __device__ __forceinline__ uint4 prologue_apply<half_t>(uint4 v, const float* pa, const float* pb) {
+    half_t* hv = reinterpret_cast<half_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float t = fmaf((float)hv[i], pa[i], pb[i]);
+        hv[i] = (half_t)(t / (1.0f + __expf(-t)));
+    }
+    return v;
+}
+
+// WCO/WPX: 16x16 sub-tiles per wave along co / px.  NW_CO x NW_PX waves per workgroup.
+template <typename T, int WCO, int WPX, int NW_CO, int NW_PX>
+__global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int NT = 64 * NW_CO * NW_PX;
+    constexpr int TCO = 16 * WCO * NW_CO;
+    constexpr int TPX = 16 * WPX * NW_PX;
+    constexpr int VEC = DT<T>::VEC;       // elements per 16 B
+    constexpr int KC = 4 * VEC;           // elements per 64-byte LDS row
+    constexpr int A_CHUNKS = TCO * 4;     // 16-byte chunks of the weight tile
+    constexpr int B_CHUNKS = TPX * 4;
+    constexpr int A_PER = (A_CHUNKS + NT - 1) / NT;
+    constexpr int B_PER = (B_CHUNKS + NT - 1) / NT;
+    constexpr int A_BYTES = TCO * 64, B_BYTES = TPX * 64;
+    typedef typename Frag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto lds_a = [&](int buf) -> char* { return smem + buf * (A_BYTES + B_BYTES); };
+    auto lds_b = [&](int buf) -> char* { return smem + buf * (A_BYTES + B_BYTES) + A_BYTES; };
+
+    // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a
+    // contiguous range of logical tiles so that the co-tiles of one pixel tile, and vertically
+    // adjacent pixel tiles, hit the same L2.
+    long long nblk = (long long)p.n_co_tiles * p.n_px_tiles;
+    long long bid = blockIdx.x;
+    {
+        long long q = nblk / 8, r = nblk % 8;
+        long long xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int co_tile = (int)(bid % p.n_co_tiles);
+    const long long px_tile = bid / p.n_co_tiles;
+    const int co0 = co_tile * TCO;
+    const long long m0 = px_tile * TPX;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int w_co = wave / NW_PX, w_px = wave % NW_PX;
+
+    // ---- per-thread staging state for the pixel rows this thread loads
+    int b_row[B_PER], b_q[B_PER], b_oy[B_PER], b_ox[B_PER];
+    long long b_nbase[B_PER];  // element offset of image n in input 1 (per pitch unit: pixels)
+    bool b_ok[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        int chunk = tid + i * NT;
+        b_row[i] = chunk >> 2;
+        b_q[i] = chunk & 3;
+        long long m = m0 + b_row[i];
+        b_ok[i] = (chunk < B_CHUNKS) && (m < p.M);
+        long long mm = b_ok[i] ? m : 0;
+        int hw = p.ho * p.wo;
+        int nimg = (int)(mm / hw);
+        int rem = (int)(mm - (long long)nimg * hw);
+        b_oy[i] = rem / p.wo;
+        b_ox[i] = rem - b_oy[i] * p.wo;
+        b_nbase[i] = (long long)nimg * p.h * p.w_in;
+    }
+    const int lh = p.upsample ? p.h * 2 : p.h;   // logical input size seen by the conv
+    const int lw = p.upsample ? p.w_in * 2 : p.w_in;
+    const int ntaps = p.ksize * p.ksize;
+    const int nsteps = ntaps * p.nkc;
+
+    uint4 ra[A_PER], rb[B_PER];
+
+    auto load_step = [&](int s) {
+        int tap = s / p.nkc, kc = s - tap * p.nkc;
+        int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        // weights: linear 64-byte rows
+        const char* wsrc = (const char*)p.w + ((long long)(tap * p.nkc + kc) * p.co_pad + co0) * 64;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int chunk = tid + i * NT;
+            if (chunk < A_CHUNKS) ra[i] = *reinterpret_cast<const uint4*>(wsrc + (long long)chunk * 16);
+        }
+        // activations: per-pixel gather of one 16-byte channel chunk
+        const bool second = kc >= p.nkc1;
+        const char* xsrc = (const char*)(second ? p.x2 : p.x);
+        const int pitch = second ? p.cin2_pitch : p.cin_pitch;
+        const int cvalid = second ? p.cin2 : p.cin;
+        const int kcl = second ? kc - p.nkc1 : kc;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            int iy = b_oy[i] * p.stride + ky - p.pad;
+            int ix = b_ox[i] * p.stride + kx - p.pad;
+            int c0 = kcl * KC + b_q[i] * VEC;
+            if (b_ok[i] && iy >= 0 && iy < lh && ix >= 0 && ix < lw && c0 < pitch) {
+                int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+                long long e = (b_nbase[i] + (long long)sy * p.w_in + sx) * pitch + c0;
+                v = *reinterpret_cast<const uint4*>(xsrc + e * (long long)sizeof(T));
+                if (p.prologue) {
+                    int nimg = (int)(b_nbase[i] / ((long long)p.h * p.w_in));
+                    const float* pa = p.pa + (long long)nimg * (p.cin + p.cin2) + (second ? p.cin : 0) + c0;
+                    const float* pb = p.pb + (long long)nimg * (p.cin + p.cin2) + (second ? p.cin : 0) + c0;
+                    float la[VEC], lb[VEC];
+#pragma unroll
+                    for (int e2 = 0; e2 < VEC; ++e2) {
+                        bool in = (c0 + e2) < cvalid;
+                        la[e2] = in ? pa[e2] : 0.0f;
+                        lb[e2] = in ? pb[e2] : 0.0f;
+                    }
+                    v = prologue_apply<T>(v, la, lb);
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int chunk = tid + i * NT;
+            if (chunk < A_CHUNKS) *reinterpret_cast<uint4*>(lds_a(buf) + lds_row_off(chunk >> 2, chunk & 3)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            int chunk = tid + i * NT;
+            if (chunk < B_CHUNKS) *reinterpret_cast<uint4*>(lds_b(buf) + lds_row_off(b_row[i], b_q[i])) = rb[i];
+        }
+    };
+
+    float4v acc[WCO][WPX];
+#pragma unroll
+    for (int i = 0; i < WCO; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int lane_off = lds_row_off(lane & 15, lane >> 4);
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_step(s + 1);
+        frag_t fa[WCO], fb[WPX];
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+            fa[i] = *reinterpret_cast<const frag_t*>(lds_a(buf) + (w_co * WCO + i) * 1024 + lane_off);
+#pragma unroll
+        for (int j = 0; j < WPX; ++j)
+            fb[j] = *reinterpret_cast<const frag_t*>(lds_b(buf) + (w_px * WPX + j) * 1024 + lane_off);
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) mma_tile(acc[i][j], fa[i], fb[j]);
+        if (s + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds co = cobase + (lane>>4)*4 + r (r=0..3) for pixel col = lane&15
+    const int cgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        long long m = m0 + (w_px * WPX + j) * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < WCO; ++i) {
+            int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+            if (co >= p.cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            int nv = p.cout - co < 4 ? p.cout - co : 4;
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nv) v[r] += p.bias[co + r];
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            }
+            if (p.res) {
+                const T* rp = (const T*)p.res + m * p.res_pitch + co;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nv) v[r] += to_f(rp[r]);
+            }
+            T* op = (T*)p.out + m * p.cout_pitch + co;
+            if (nv == 4) {
+                if constexpr (sizeof(T) == 2) {
+                    half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4*>(op) = hv;
+                } else {
+                    *reinterpret_cast<float4v*>(op) = (float4v){v[0], v[1], v[2], v[3]};
+                }
+            } else {
+                for (int r = 0; r < nv; ++r) op[r] = from_f<T>(v[r]);
+            }
+        }
+    }
+}
+
+// tile configuration chosen from cout (shared by pack + launch)
+struct TileCfg {
+    int tco, tpx, id;
+};
+inline TileCfg choose_tile(int cout) {
+    if (cout % 128 == 0) return {128, 128, 0};
+    if (cout % 64 == 0) return {64, 128, 1};
+    if (cout <= 16) return {16, 256, 3};
+    return {32, 256, 2};
+}
+inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
+
+int validate(const elvis_conv_desc* d) {
+    ELVIS_REQUIRE(d, "conv: null descriptor");
+    ELVIS_REQUIRE(d->dtype == ELVIS_F32 || d->dtype == ELVIS_F16, "conv: bad dtype %d", d->dtype);
+    ELVIS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->ho > 0 && d->wo > 0,
+                  "conv: bad shape n=%d h=%d w=%d cin=%d cout=%d ho=%d wo=%d", d->n, d->h, d->w, d->cin, d->cout, d->ho, d->wo);
+    ELVIS_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize must be 1 or 3 (got %d)", d->ksize);
+    ELVIS_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2");
+    ELVIS_REQUIRE(d->cin_pitch >= d->cin && d->cin_pitch % 8 == 0, "conv: cin_pitch %d must be >= cin %d and a multiple of 8", d->cin_pitch, d->cin);
+    ELVIS_REQUIRE(d->cout_pitch >= d->cout && d->cout_pitch % 4 == 0, "conv: cout_pitch %d invalid for cout %d", d->cout_pitch, d->cout);
+    int kc = kc_elems(d->dtype);
+    if (d->cin2 > 0) {
+        ELVIS_REQUIRE(d->cin % kc == 0, "conv: with a second input, cin (%d) must be a multiple of %d", d->cin, kc);
+        ELVIS_REQUIRE(d->cin2_pitch >= d->cin2 && d->cin2_pitch % 8 == 0, "conv: bad cin2_pitch");
+    }
+    int lh = d->upsample ? 2 * d->h : d->h, lw = d->upsample ? 2 * d->w : d->w;
+    // last tap of the last output must start inside [-(pad), l+2): loose sanity bound
+    ELVIS_REQUIRE((long long)(d->ho - 1) * d->stride - d->pad_before < lh && (long long)(d->wo - 1) * d->stride - d->pad_before < lw,
+                  "conv: output %dx%d does not fit input %dx%d (stride %d)", d->ho, d->wo, lh, lw, d->stride);
+    return ELVIS_OK;
+}
+
+template <typename T, int WCO, int WPX, int NW_CO, int NW_PX>
+int launch(const ConvArgs& a, hipStream_t stream) {
+    constexpr int TCO = 16 * WCO * NW_CO, TPX = 16 * WPX * NW_PX;
+    size_t lds = 2 * (size_t)(TCO + TPX) * 64;
+    long long nblk = (long long)a.n_co_tiles * a.n_px_tiles;
+    ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WCO, WPX, NW_CO, NW_PX>), dim3((unsigned)nblk), dim3(64 * NW_CO * NW_PX),
+                       lds, stream, a);
+    ELVIS_CHECK_LAUNCH("elvis_conv2d");
+    return ELVIS_OK;
+}
+
+template <typename T> int dispatch(const ConvArgs& a, int id, hipStream_t stream) {
+    switch (id) {
+        case 0: return launch<T, 4, 4, 2, 2>(a, stream);
+        case 1: return launch<T, 2, 4, 2, 2>(a, stream);
+        case 2: return launch<T, 2, 4, 1, 4>(a, stream);
+        default: return launch<T, 1, 4, 1, 4>(a, stream);
+    }
+}
+
+// ---- weight packing: OIHW f32 -> [tap][kc][co_pad][KC] (T)
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int ctot, int ks,
+                                    int nkc, int co_pad, int KC, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int k = (int)(i % KC);
+    long long t = i / KC;
+    int co = (int)(t % co_pad);
+    t /= co_pad;
+    int kc = (int)(t % nkc);
+    int tap = (int)(t / nkc);
+    int ci = kc * KC + k;
+    float v = 0.f;
+    if (co < cout && ci < ctot) v = w[((long long)co * ctot + ci) * ks * ks + tap];
+    out[i] = from_f<T>(v);
+}
+
+}  // namespace
+
+static void conv_geom(const elvis_conv_desc* d, int* nkc1, int* nkc, int* co_pad) {
+    int kc = kc_elems(d->dtype);
+    *nkc1 = (d->cin + kc - 1) / kc;
+    *nkc = *nkc1 + (d->cin2 > 0 ? (d->cin2 + kc - 1) / kc : 0);
+    TileCfg t = choose_tile(d->cout);
+    *co_pad = ((d->cout + t.tco - 1) / t.tco) * t.tco;
+}
+
+extern "C" size_t elvis_conv_packed_weight_bytes(const elvis_conv_desc* d) {
+    if (!d || d->cin <= 0 || d->cout <= 0) return 0;
+    int nkc1, nkc, co_pad;
+    conv_geom(d, &nkc1, &nkc, &co_pad);
+    return (size_t)d->ksize * d->ksize * nkc * co_pad * 64;
+}
+
+extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_oihw, void* packed,
+                                       elvis_stream_t stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    ELVIS_REQUIRE(w_oihw && packed, "elvis_conv_pack_weights: null pointer");
+    int nkc1, nkc, co_pad;
+    conv_geom(d, &nkc1, &nkc, &co_pad);
+    int KC = kc_elems(d->dtype);
+    // with two inputs the packed K axis is [cin padded to nkc1*KC | cin2]; cin % KC == 0 is
+    // enforced in that case so the source channel index is simply ci.
+    long long total = (long long)d->ksize * d->ksize * nkc * co_pad * KC;
+    int grid = (int)((total + 255) / 256);
+    int ctot = d->cin + d->cin2;
+    if (d->dtype == ELVIS_F16)
+        hipLaunchKernelGGL(pack_weights_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (half_t*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (float*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total);
+    ELVIS_CHECK_LAUNCH("elvis_conv_pack_weights");
+    return ELVIS_OK;
+}
+
+extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const void* w_packed,
+                            const float* bias, const void* residual, int residual_pitch, const float* pa,
+                            const float* pb, void* out, elvis_stream_t stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    ELVIS_REQUIRE(x && w_packed && out, "elvis_conv2d: null pointer");
+    ELVIS_REQUIRE(d->cin2 == 0 || x2, "elvis_conv2d: cin2 > 0 but x2 is null");
+    ELVIS_REQUIRE(!d->prologue || (pa && pb), "elvis_conv2d: prologue requested without pa/pb");
+    ELVIS_REQUIRE(!residual || residual_pitch >= d->cout, "elvis_conv2d: bad residual pitch");
+    ELVIS_REQUIRE(((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_packed | (uintptr_t)out) % 16 == 0,
+                  "elvis_conv2d: pointers must be 16-byte aligned");
+    ConvArgs a;
+    a.x = x; a.x2 = x2; a.w = w_packed; a.bias = bias; a.res = residual; a.pa = pa; a.pb = pb; a.out = out;
+    a.n = d->n; a.h = d->h; a.w_in = d->w;
+    a.cin = d->cin; a.cin_pitch = d->cin_pitch; a.cin2 = d->cin2; a.cin2_pitch = d->cin2_pitch;
+    a.cout = d->cout; a.cout_pitch = d->cout_pitch; a.res_pitch = residual_pitch;
+    a.ksize = d->ksize; a.stride = d->stride; a.pad = d->pad_before; a.upsample = d->upsample;
+    a.ho = d->ho; a.wo = d->wo; a.act = d->act; a.prologue = d->prologue;
+    conv_geom(d, &a.nkc1, &a.nkc, &a.co_pad);
+    TileCfg t = choose_tile(d->cout);
+    a.M = (long long)d->n * d->ho * d->wo;
+    a.n_co_tiles = a.co_pad / t.tco;
+    a.n_px_tiles = (a.M + t.tpx - 1) / t.tpx;
+    if (d->dtype == ELVIS_F16) return dispatch<half_t>(a, t.id, (hipStream_t)stream);
+    return dispatch<float>(a, t.id, (hipStream_t)stream);
+}

@@ -1,0 +1,282 @@
+"""Tensor-level wrappers over the C ABI (device memory and streams come from torch - plumbing
+only; every arithmetic op below is a hand-written HIP kernel in libelvis_amd.so).
+
+Float activations are NHWC torch tensors of shape [n, h, w, pitch] (pitch = channel stride, a
+multiple of 8, pad channels are kept at zero) accompanied by the logical channel count.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, check, lib, ptr
+
+
+def _s(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def pitch_for(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+@dataclass
+class Act:
+    """NHWC activation: t[n,h,w,pitch], logical channels c."""
+    t: torch.Tensor
+    c: int
+
+    @property
+    def n(self): return self.t.shape[0]
+    @property
+    def h(self): return self.t.shape[1]
+    @property
+    def w(self): return self.t.shape[2]
+    @property
+    def pitch(self): return self.t.shape[3]
+    @property
+    def dtype_code(self): return L.dtype_code(self.t.dtype)
+
+
+def new_act(n, h, w, c, dtype, device, zero=None) -> Act:
+    p = pitch_for(c)
+    need_zero = (p != c) if zero is None else zero
+    f = torch.zeros if need_zero else torch.empty
+    return Act(f((n, h, w, p), dtype=dtype, device=device), c)
+
+
+# ----------------------------------------------------------------------------- u8 glue
+def _chk_u8(*ts):
+    for t in ts:
+        if t.dtype != torch.uint8 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("expected contiguous CUDA uint8 tensors")
+
+
+def recompose_u8(a, b, map_i32, block, thr, out=None, map_out=None, clamp_to=0):
+    """out = (map <= thr) ? a : b per block.  a,b: [n,h,w,c] u8; map: [n,by,bx] int32."""
+    _chk_u8(a, b)
+    if a.shape != b.shape:
+        raise ValueError(f"recompose: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    n, h, w, c = a.shape
+    if map_i32.dtype != torch.int32 or map_i32.dim() != 3 or map_i32.shape[0] != n:
+        raise ValueError("recompose: map must be int32 [n,by,bx]")
+    map_i32 = map_i32.contiguous()
+    by, bx = map_i32.shape[1:]
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().elvis_recompose_u8(ptr(a), ptr(b), ptr(map_i32), ptr(out), ptr(map_out), n, h, w, c, block, by, bx,
+                                   int(thr), int(clamp_to), _s(a)), a.device)
+    return out
+
+
+def area_downscale_u8(src, factor, rounding=L.ROUND_CV2, out=None):
+    _chk_u8(src)
+    n, h, w, c = src.shape
+    if h % factor or w % factor:
+        raise ValueError("area_downscale_u8 needs H,W divisible by the factor")
+    if out is None:
+        out = torch.empty((n, h // factor, w // factor, c), dtype=torch.uint8, device=src.device)
+    check(lib().elvis_area_downscale_u8(ptr(src), ptr(out), n, h, w, c, factor, rounding, _s(src)), src.device)
+    return out
+
+
+def blend_u8(orig, rest, map_i32, block, alpha, out=None):
+    _chk_u8(orig, rest)
+    n, h, w, c = orig.shape
+    map_i32 = map_i32.contiguous()
+    by, bx = map_i32.shape[1:]
+    if out is None:
+        out = torch.empty_like(orig)
+    check(lib().elvis_blend_u8(ptr(orig), ptr(rest), ptr(map_i32), ptr(out), n, h, w, c, block, by, bx, float(alpha),
+                               _s(orig)), orig.device)
+    return out
+
+
+def select_levels_u8(versions, slot_of_level, map_i32, block, out=None):
+    """versions: list of [n,h,w,c] u8 tensors; slot_of_level: int32 tensor level->index (-1 = none)."""
+    _chk_u8(*versions)
+    n, h, w, c = versions[0].shape
+    dev = versions[0].device
+    ptrs = torch.tensor([v.data_ptr() for v in versions], dtype=torch.int64, device=dev)
+    map_i32 = map_i32.contiguous()
+    by, bx = map_i32.shape[1:]
+    if out is None:
+        out = torch.empty_like(versions[0])
+    check(lib().elvis_select_levels_u8(ptr(ptrs), ptr(slot_of_level), slot_of_level.numel(), ptr(map_i32), ptr(out),
+                                       n, h, w, c, block, by, bx, _s(out)), dev)
+    return out
+
+
+def tile_accumulate(acc, wsum, tile, wy, wx, wx2, y0, x0, temporal_weight):
+    h, w, c = acc.shape
+    th, tw = tile.shape[:2]
+    check(lib().elvis_tile_accumulate_f32(ptr(acc), ptr(wsum), ptr(tile), ptr(wy), ptr(wx), ptr(wx2), h, w, y0, x0, th, tw, c,
+                                          float(temporal_weight), _s(acc)), acc.device)
+
+
+def tile_normalize(acc, wsum, out=None):
+    h, w, c = acc.shape
+    if out is None:
+        out = torch.empty((h, w, c), dtype=torch.uint8, device=acc.device)
+    check(lib().elvis_tile_normalize_u8(ptr(acc), ptr(wsum), ptr(out), h, w, c, _s(acc)), acc.device)
+    return out
+
+
+def sse_u8(a, b, mask=None):
+    """Per-frame (sum of squared differences, element count) as int64 tensors."""
+    _chk_u8(a, b)
+    n, h, w, c = a.shape
+    sse = torch.zeros(n, dtype=torch.int64, device=a.device)
+    cnt = torch.zeros(n, dtype=torch.int64, device=a.device)
+    check(lib().elvis_sse_u8(ptr(a), ptr(b), ptr(mask), ptr(sse), ptr(cnt), n, h, w, c, _s(a)), a.device)
+    return sse, cnt
+
+
+# ----------------------------------------------------------------------------- conversions
+def u8_to_float(src, dtype, scale, bias, swap_rb=False, div255=False, pitch=8) -> Act:
+    _chk_u8(src)
+    n, h, w, c = src.shape
+    if c != 3:
+        raise ValueError("u8_to_float expects 3-channel frames")
+    dst = torch.empty((n, h, w, pitch), dtype=dtype, device=src.device)
+    check(lib().elvis_u8_to_float(ptr(src), ptr(dst), L.dtype_code(dtype), n, h, w, pitch, float(scale), float(bias),
+                                  int(swap_rb), int(div255), _s(src)), src.device)
+    return Act(dst, 3)
+
+
+def float_to_u8(x: Act, scale, bias, mode=0, swap_rb=False, want_f32=False):
+    n, h, w = x.n, x.h, x.w
+    dst = torch.empty((n, h, w, 3), dtype=torch.uint8, device=x.t.device)
+    f32 = torch.empty((n, h, w, 3), dtype=torch.float32, device=x.t.device) if want_f32 else None
+    check(lib().elvis_float_to_u8(ptr(x.t), x.dtype_code, ptr(dst), ptr(f32), n, h, w, x.pitch, float(scale),
+                                  float(bias), mode, int(swap_rb), _s(x.t)), x.t.device)
+    return (dst, f32) if want_f32 else dst
+
+
+# ----------------------------------------------------------------------------- model kernels
+class PackedConv:
+    """A conv/linear layer with weights packed for the implicit-GEMM kernel."""
+
+    def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int,
+                 cin2: int = 0):
+        cout, ctot, kh, kw = weight_oihw.shape
+        assert kh == kw and ctot == cin + cin2
+        self.cin, self.cin2, self.cout, self.ksize = cin, cin2, cout, kh
+        self.dtype, self.device = dtype, device
+        d = ConvDesc()
+        d.dtype = L.dtype_code(dtype)
+        d.n = d.h = d.w = d.ho = d.wo = 1
+        d.cin, d.cin_pitch, d.cin2, d.cin2_pitch = cin, pitch_for(cin), cin2, pitch_for(cin2) if cin2 else 0
+        d.cout, d.cout_pitch = cout, pitch_for(cout)
+        d.ksize, d.stride = kh, 1
+        nbytes = lib().elvis_conv_packed_weight_bytes(C.byref(d))
+        w_dev = weight_oihw.to(device=device, dtype=torch.float32).contiguous()
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(lib().elvis_conv_pack_weights(C.byref(d), ptr(w_dev), ptr(self.packed), _s(self.packed)), device)
+        torch.cuda.current_stream(device).synchronize()  # w_dev may be freed after return
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+
+    def __call__(self, x: Act, x2: Optional[Act] = None, *, stride=1, pad=None, upsample=False, act=0,
+                 residual: Optional[Act] = None, prologue=None, out: Optional[Act] = None, ho=None, wo=None) -> Act:
+        if x.c != self.cin or (x2.c if x2 is not None else 0) != self.cin2:
+            raise ValueError(f"conv: expected inputs with {self.cin}+{self.cin2} channels, got {x.c}+{x2.c if x2 else 0}")
+        d = ConvDesc()
+        d.dtype = x.dtype_code
+        d.n, d.h, d.w = x.n, x.h, x.w
+        d.cin, d.cin_pitch = x.c, x.pitch
+        d.cin2, d.cin2_pitch = (x2.c, x2.pitch) if x2 is not None else (0, 0)
+        d.ksize, d.stride, d.upsample, d.act = self.ksize, stride, int(upsample), act
+        d.pad_before = (self.ksize // 2) if pad is None else pad
+        lh, lw = (x.h * 2, x.w * 2) if upsample else (x.h, x.w)
+        if ho is None:
+            ho = (lh + 2 * d.pad_before - self.ksize) // stride + 1
+            wo = (lw + 2 * d.pad_before - self.ksize) // stride + 1
+        d.ho, d.wo = ho, wo
+        if out is None:
+            out = new_act(x.n, ho, wo, self.cout, x.t.dtype, x.t.device)
+        d.cout, d.cout_pitch = self.cout, out.pitch
+        pa = pb = None
+        if prologue is not None:
+            pa, pb = prologue
+            d.prologue = 1
+        check(lib().elvis_conv2d(C.byref(d), ptr(x.t), ptr(x2.t) if x2 is not None else 0, ptr(self.packed),
+                                 ptr(self.bias), ptr(residual.t) if residual is not None else 0,
+                                 residual.pitch if residual is not None else 0, ptr(pa), ptr(pb), ptr(out.t),
+                                 _s(x.t)), x.t.device)
+        return out
+
+
+def groupnorm_affine(xs, gamma, beta, groups, eps, scale=None, shift=None):
+    """GroupNorm statistics over the (virtual) channel concat of `xs` -> per-(n,c) affine (pa, pb)
+    such that GN(x)*(1+scale)+shift == x*pa + pb."""
+    x0 = xs[0]
+    n, hw = x0.n, x0.h * x0.w
+    ctot = sum(x.c for x in xs)
+    dev = x0.t.device
+    sums = torch.zeros((n, ctot, 2), dtype=torch.float64, device=dev)
+    off = 0
+    for x in xs:
+        check(lib().elvis_groupnorm_sums(ptr(x.t), x.dtype_code, n, hw, x.c, x.pitch, ptr(sums), ctot, off, _s(x.t)), dev)
+        off += x.c
+    pa = torch.empty((n, ctot), dtype=torch.float32, device=dev)
+    pb = torch.empty((n, ctot), dtype=torch.float32, device=dev)
+    check(lib().elvis_groupnorm_affine(ptr(sums), ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ptr(pa), ptr(pb), n,
+                                       hw, ctot, groups, float(eps), _s(x0.t)), dev)
+    return pa, pb
+
+
+def affine_act(x: Act, pa, pb, act=2, out: Optional[Act] = None) -> Act:
+    if out is None:
+        out = new_act(x.n, x.h, x.w, x.c, x.t.dtype, x.t.device, zero=False)
+    check(lib().elvis_affine_act(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h * x.w, x.c, x.pitch, out.pitch, ptr(pa),
+                                 ptr(pb), act, _s(x.t)), x.t.device)
+    return out
+
+
+def layernorm(x: Act, gamma, beta, eps=1e-5, out: Optional[Act] = None) -> Act:
+    if out is None:
+        out = new_act(x.n, x.h, x.w, x.c, x.t.dtype, x.t.device, zero=False)
+    check(lib().elvis_layernorm(ptr(x.t), ptr(out.t), x.dtype_code, x.n * x.h * x.w, x.c, x.pitch, out.pitch,
+                                ptr(gamma), ptr(beta), float(eps), _s(x.t)), x.t.device)
+    return out
+
+
+def window_attention(qkv: Act, heads, head_dim, ws, shift, bias_table, scale) -> Act:
+    out = new_act(qkv.n, qkv.h, qkv.w, heads * head_dim, qkv.t.dtype, qkv.t.device, zero=False)
+    check(lib().elvis_window_attention(ptr(qkv.t), ptr(out.t), qkv.dtype_code, qkv.n, qkv.h, qkv.w, heads, head_dim,
+                                       ws, shift, qkv.pitch, out.pitch, ptr(bias_table), float(scale), _s(qkv.t)),
+          qkv.t.device)
+    return out
+
+
+def bicubic_upsample(x: Act, sf: int) -> Act:
+    out = new_act(x.n, x.h * sf, x.w * sf, x.c, x.t.dtype, x.t.device, zero=False)
+    check(lib().elvis_bicubic_upsample(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c, x.pitch, out.pitch, sf,
+                                       _s(x.t)), x.t.device)
+    return out
+
+
+def vq_nearest(z: Act, codebook: torch.Tensor, want_idx=False):
+    out = new_act(z.n, z.h, z.w, z.c, z.t.dtype, z.t.device, zero=False)
+    idx = torch.empty((z.n, z.h, z.w), dtype=torch.int32, device=z.t.device) if want_idx else None
+    check(lib().elvis_vq_nearest(ptr(z.t), ptr(out.t), ptr(idx), z.dtype_code, z.n * z.h * z.w, z.c, z.pitch,
+                                 out.pitch, ptr(codebook), codebook.shape[0], _s(z.t)), z.t.device)
+    return (out, idx) if want_idx else out
+
+
+def pad_reflect_axpy(x: Act, hp, wp, out: Act, ch_offset=0, mul=1.0, add=None, add_mul=0.0):
+    check(lib().elvis_pad_reflect_axpy(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c, x.pitch, hp, wp,
+                                       out.pitch, ch_offset, float(mul), ptr(add), float(add_mul), _s(x.t)),
+          x.t.device)
+    return out
+
+
+def crop_copy(x: Act, h, w) -> Act:
+    out = new_act(x.n, h, w, x.c, x.t.dtype, x.t.device, zero=False)
+    check(lib().elvis_crop_copy(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.pitch, h, w, x.c, out.pitch,
+                                _s(x.t)), x.t.device)
+    return out

@@ -1,0 +1,162 @@
+"""Frames-in / frames-out restoration drivers: the reference's P1/P2/P3 protocols backed by the
+MI355X SinSR path.
+
+  P1  `upsample_fn(img_bgr_u8) -> img_bgr_u8`  (elvis.py:2528, 2575)  -> `get_sinsr_upsample_fn`
+  P2  `restore_frames_sinsr(frames, downscale_maps, block_size, device, **kw)`
+      = drop-in for `restore_frames_realesrgan` (elvis.py:2640-2682)
+  P3  `restore_with_sinsr_naive(frames=, device=, **kw)` resolution-preserving restore_fn
+      (signature template utils.py:1428-1473)
+
+Model handles are process-global, cached per (device, params) under a lock like
+`get_realesrgan_upsampler` (elvis.py:2607-2637).
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .recompose import (frames_to_device, frames_to_host, maps_to_device, rounds_recompose_device,
+                        upscale_adaptive_device)
+from .sinsr import SinSRModel
+from .weights import SinSRConfig
+
+_MODEL_CACHE: Dict[str, SinSRModel] = {}
+_MODEL_LOCK = threading.Lock()
+DEFAULT_SEED = 42  # the reference's default sampler seed (elvis.py:89, utils.py:103)
+
+
+def get_sinsr_model(device, *, cfg: Optional[SinSRConfig] = None, fp32: bool = False, weight_seed: int = 0,
+                    state_dict=None, fuse_gn: bool = False) -> SinSRModel:
+    """Get or create the cached SinSR runtime for `device` (thread-safe, never freed - the
+    reference's cache policy, elvis.py:2611-2637)."""
+    dev = torch.device(device)
+    L.require_gpu(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = cfg or SinSRConfig()
+    key = f"{dev}_{hash(cfg)}_{fp32}_{weight_seed}_{id(state_dict) if state_dict is not None else 0}_{fuse_gn}"
+    with _MODEL_LOCK:
+        m = _MODEL_CACHE.get(key)
+        if m is None:
+            try:
+                m = SinSRModel(cfg, state_dict, dev, torch.float32 if fp32 else torch.float16, weight_seed, fuse_gn)
+            except RuntimeError as exc:
+                raise RuntimeError(f"SinSR failed on {dev}: {exc}") from exc
+            _MODEL_CACHE[key] = m
+    return m
+
+
+def sr4x_device(model: SinSRModel, lr_d: torch.Tensor, frame_indices: Sequence[int], seed: int = DEFAULT_SEED,
+                swap_rb: bool = True, batch: int = 1) -> torch.Tensor:
+    """[n,h,w,3] u8 -> [n,4h,4w,3] u8 on device; sampler noise keyed on the global frame index."""
+    n, h, w, _ = lr_d.shape
+    outs = []
+    with torch.cuda.device(model.device):
+        for s in range(0, n, batch):
+            idx = list(frame_indices[s:s + batch])
+            noise = model.make_noise(seed, idx, h, w)
+            outs.append(model.forward(lr_d[s:s + batch].contiguous(), noise, swap_rb=swap_rb))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+def get_sinsr_upsample_fn(device, *, scale: int = 2, seed: int = DEFAULT_SEED, frame_index: int = 0,
+                          fp32: bool = False, cfg: Optional[SinSRConfig] = None) -> Callable[[np.ndarray], np.ndarray]:
+    """P1: "a single 2x upscale" of a BGR uint8 HWC image (elvis.py:2528, 2548, 2575).  scale=2
+    runs the 4x network and area-halves the result (what RealESRGANer.enhance(outscale=2) does
+    with its x4 net, elvis.py:2515); scale=4 returns the native 4x output."""
+    if scale not in (2, 4):
+        raise ValueError("scale must be 2 or 4")
+    model = get_sinsr_model(device, cfg=cfg, fp32=fp32)
+
+    def upsample_fn(img: np.ndarray) -> np.ndarray:
+        try:
+            d = frames_to_device([img], model.device)
+            out = sr4x_device(model, d, [frame_index], seed)
+            if scale == 2:
+                out = ops.area_downscale_u8(out, 2)
+            return frames_to_host(out)[0]
+        except RuntimeError as exc:
+            raise RuntimeError(f"SinSR failed on {model.device}: {exc}") from exc
+
+    return upsample_fn
+
+
+def restore_frames_sinsr(frames: List[np.ndarray], downscale_maps: np.ndarray, block_size: int, device,
+                         *, seed: int = DEFAULT_SEED, first_frame_index: int = 0, fp32: bool = False,
+                         staged_2x: bool = False, cfg: Optional[SinSRConfig] = None, **_ignored) -> List[np.ndarray]:
+    """Pure restoration function (no file IO, no parallelisation), drop-in for
+    `restore_frames_realesrgan` (elvis.py:2640-2682): BGR uint8 frames + per-block log2
+    downscale maps -> restored frames.
+
+    Default: native 4x stages (one SinSR call from the /4 level, README.md:50).  `staged_2x=True`
+    reproduces the reference's 2x-per-stage loop with the 4x net area-halved per stage.
+    Unknown model kwargs of the reference call (model_name, tile, ...) are accepted and ignored
+    (the `**kwargs` convention of the P3 surface, utils.py:1428).
+    """
+    if not frames:
+        return []
+    dev = torch.device(device)
+    model = get_sinsr_model(dev, cfg=cfg, fp32=fp32)
+    with torch.cuda.device(model.device):
+        frames_d = frames_to_device(frames, model.device)
+        n = frames_d.shape[0]
+        maps_d = maps_to_device(downscale_maps, n, model.device)
+        out = torch.empty_like(frames_d)
+        # the reference derives the stage schedule from each frame's own max level
+        # (elvis.py:2561): group frames by it so a batch shares one schedule.
+        maxlv = maps_d.flatten(1).max(dim=1).values.tolist()
+        for lv in sorted(set(maxlv)):
+            idx = [i for i, v in enumerate(maxlv) if v == lv]
+            if lv == 0:
+                out[idx] = frames_d[idx]
+                continue
+            it = torch.tensor(idx, device=model.device)
+            sub_f, sub_m = frames_d[it].contiguous(), maps_d[it].contiguous()
+            gidx = [first_frame_index + i for i in idx]
+
+            def up(cur, _g=gidx):
+                return sr4x_device(model, cur, _g, seed)
+
+            out[it] = upscale_adaptive_device(sub_f, sub_m, block_size, up, sr_scale=2 if staged_2x else 4)
+        return frames_to_host(out)
+
+
+def restore_with_sinsr_naive(frames: List[np.ndarray], device="cuda", seed: int = DEFAULT_SEED,
+                             tile_coords=None, degradation_level=None, **kwargs) -> List[np.ndarray]:
+    """P3 restore_fn: resolution-preserving whole-frame restore of RGB uint8 frames - /4 area
+    downscale, SinSR 4x back to size (the shape of restore_with_realesrgan_naive, utils.py:1428,
+    which runs the 4x net and resizes back).  Accepts and ignores unknown kwargs."""
+    if not frames:
+        return []
+    dev = torch.device("cuda:0" if str(device) == "cuda" else device)
+    model = get_sinsr_model(dev, fp32=bool(kwargs.get("fp32", False)), cfg=kwargs.get("cfg"))
+    t0 = tile_coords[0] if tile_coords else 0
+    with torch.cuda.device(model.device):
+        d = frames_to_device(frames, model.device)
+        n, h, w, _ = d.shape
+        ph, pw = (-h) % 4, (-w) % 4
+        if ph or pw:
+            raise ValueError("restore_with_sinsr_naive needs H,W divisible by 4")
+        lr = ops.area_downscale_u8(d, 4)
+        out = sr4x_device(model, lr, [t0 + i for i in range(n)], seed, swap_rb=False)
+        return frames_to_host(out)
+
+
+def restore_frames_rounds(frames: List[np.ndarray], maps: np.ndarray, block_size: int, device,
+                          restore_dev: Callable[[torch.Tensor], torch.Tensor], batch_size: int = 4,
+                          max_rounds: Optional[int] = None) -> List[np.ndarray]:
+    """Frames-level form of the iterative round loop (elvis.py:2947-2981) for any on-device
+    restorer (`restore_dev`: [n,H,W,3] u8 -> same) - the slot the Blur / DCT restorers fill."""
+    if not frames:
+        return []
+    dev = torch.device(device)
+    L.require_gpu(dev)
+    with torch.cuda.device(dev):
+        frames_d = frames_to_device(frames, dev)
+        maps_d = maps_to_device(maps, frames_d.shape[0], dev)
+        return frames_to_host(rounds_recompose_device(frames_d, maps_d, block_size, restore_dev, batch_size, max_rounds))

@@ -1,0 +1,311 @@
+"""Device graph of the SinSR-style single-step 4x super-resolver (ELVIS v2 Downsample slot).
+
+This fills the model slot where the reference calls `RealESRGANer.enhance`
+(elvis.py:2507-2519, a5 in SURVEY.md 8a); the north star names SinSR (README.md:27-28,46,50),
+whose code is absent from the reference, so the architecture is the published
+SinSR/ResShift recipe with hyper-parameters in `weights.SinSRConfig`.
+
+Every arithmetic op is a libelvis_amd.so kernel (ops.py); torch only owns the HBM buffers
+and the stream.  NHWC throughout; `dtype=torch.float32` is the exact-parity mode (fp32 MFMA),
+`torch.float16` the fast mode (f16 MFMA, fp32 accumulate).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import Act, PackedConv
+from .weights import SinSRConfig, frame_noise, make_sinsr_weights, timestep_embedding, unet_layout
+
+
+class _GN:
+    def __init__(self, sd, p, device):
+        self.gamma = sd[p + ".weight"].to(device=device, dtype=torch.float32).contiguous()
+        self.beta = sd[p + ".bias"].to(device=device, dtype=torch.float32).contiguous()
+
+
+def _conv(sd, p, dtype, device, cin, cin2=0) -> PackedConv:
+    return PackedConv(sd[p + ".weight"], sd[p + ".bias"], dtype, device, cin, cin2)
+
+
+def _linear(sd, p, dtype, device) -> PackedConv:
+    w = sd[p + ".weight"]
+    return PackedConv(w[:, :, None, None], sd.get(p + ".bias"), dtype, device, w.shape[1])
+
+
+class _ResBlock:
+    """GN -> SiLU -> conv3x3 -> GN(*(1+scale)+shift) -> SiLU -> conv3x3, + skip.
+    Serves both the UNet ResBlock (scale/shift from the timestep embedding) and the
+    autoencoder ResnetBlock (no embedding)."""
+
+    def __init__(self, sd, names, cin, cin2, cout, dtype, device, groups, eps, scale=None, shift=None):
+        n1, c1, n2, c2, skip = names
+        self.groups, self.eps = groups, eps
+        self.norm1, self.norm2 = _GN(sd, n1, device), _GN(sd, n2, device)
+        self.conv1 = _conv(sd, c1, dtype, device, cin, cin2)
+        self.conv2 = _conv(sd, c2, dtype, device, cout)
+        self.skip = _conv(sd, skip, dtype, device, cin, cin2) if (skip + ".weight") in sd else None
+        self.scale, self.shift = scale, shift
+        if self.skip is None and cin2:
+            raise ValueError("a concatenated input needs a skip projection")
+
+    def __call__(self, x: Act, x2: Optional[Act] = None, fuse_gn=False) -> Act:
+        xs = [x] if x2 is None else [x, x2]
+        pa, pb = ops.groupnorm_affine(xs, self.norm1.gamma, self.norm1.beta, self.groups, self.eps)
+        if fuse_gn:
+            h = self.conv1(x, x2, prologue=(pa, pb))
+        else:
+            a1 = ops.affine_act(x, pa[:, :x.c].contiguous(), pb[:, :x.c].contiguous(), act=2)
+            a2 = None
+            if x2 is not None:
+                a2 = ops.affine_act(x2, pa[:, x.c:].contiguous(), pb[:, x.c:].contiguous(), act=2)
+            h = self.conv1(a1, a2)
+            del a1, a2
+        pa, pb = ops.groupnorm_affine([h], self.norm2.gamma, self.norm2.beta, self.groups, self.eps,
+                                      scale=self.scale, shift=self.shift)
+        res = x if self.skip is None else self.skip(x, x2)
+        if fuse_gn:
+            return self.conv2(h, prologue=(pa, pb), residual=res)
+        ops.affine_act(h, pa, pb, act=2, out=h)
+        return self.conv2(h, residual=res)
+
+
+class _SwinLayer:
+    def __init__(self, sd, p, ch, cfg: SinSRConfig, dtype, device):
+        E = cfg.swin_embed_dim
+        self.cfg = cfg
+        f32 = dict(device=device, dtype=torch.float32)
+        self.embed = _conv(sd, p + ".patch_embed.proj", dtype, device, ch)
+        self.embed_norm = (sd[p + ".patch_embed.norm.weight"].to(**f32), sd[p + ".patch_embed.norm.bias"].to(**f32))
+        self.blocks = []
+        for d in range(cfg.swin_depth):
+            b = f"{p}.blocks.{d}"
+            self.blocks.append(dict(
+                n1=(sd[b + ".norm1.weight"].to(**f32), sd[b + ".norm1.bias"].to(**f32)),
+                n2=(sd[b + ".norm2.weight"].to(**f32), sd[b + ".norm2.bias"].to(**f32)),
+                qkv=_linear(sd, b + ".attn.qkv", dtype, device),
+                proj=_linear(sd, b + ".attn.proj", dtype, device),
+                fc1=_linear(sd, b + ".mlp.fc1", dtype, device),
+                fc2=_linear(sd, b + ".mlp.fc2", dtype, device),
+                table=sd[b + ".attn.relative_position_bias_table"].to(**f32).contiguous(),
+                shift=0 if d % 2 == 0 else cfg.window_size // 2))
+        self.unembed = _conv(sd, p + ".patch_unembed.proj", dtype, device, E)
+
+    def __call__(self, x: Act) -> Act:
+        cfg = self.cfg
+        y = self.embed(x)
+        ops.layernorm(y, *self.embed_norm, out=y)
+        for b in self.blocks:
+            t = ops.layernorm(y, *b["n1"])
+            qkv = b["qkv"](t)
+            a = ops.window_attention(qkv, cfg.heads, cfg.num_head_channels, cfg.window_size, b["shift"], b["table"],
+                                     cfg.num_head_channels ** -0.5)
+            del qkv
+            y = b["proj"](a, residual=y)
+            t = ops.layernorm(y, *b["n2"])
+            t = b["fc1"](t, act=1)
+            y = b["fc2"](t, residual=y)
+        return self.unembed(y)
+
+
+class SinSRModel:
+    """Weights resident in HBM, packed once; `forward` runs one batch of LR frames."""
+
+    def __init__(self, cfg: SinSRConfig = SinSRConfig(), state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = False):
+        self.cfg, self.device, self.dtype, self.fuse_gn = cfg, torch.device(device), dtype, fuse_gn
+        sd = state_dict if state_dict is not None else make_sinsr_weights(cfg, weight_seed)
+        dev = self.device
+        with torch.cuda.device(dev):
+            self._build_unet(sd)
+            self._build_ae(sd)
+        self.codebook = sd["ae.quantize.embedding.weight"].to(device=dev, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ construction
+    def _build_unet(self, sd):
+        cfg, dev, dt = self.cfg, self.device, self.dtype
+        # timestep path: load-time only, always in fp32 kernels
+        te0 = _linear(sd, "model.time_embed.0", torch.float32, dev)
+        te2 = _linear(sd, "model.time_embed.2", torch.float32, dev)
+        e = timestep_embedding(cfg.steps - 1, cfg.model_channels).to(dev)
+        e = Act(e.view(1, 1, 1, -1).contiguous(), cfg.model_channels)
+        e = te2(te0(e, act=2))                      # Linear -> SiLU -> Linear
+        ones = torch.ones((1, e.c), device=dev)
+        zeros = torch.zeros((1, e.c), device=dev)
+        silu_e = ops.affine_act(e, ones, zeros, act=2)  # emb_layers.0 = SiLU
+        plan = unet_layout(cfg)
+        self.plan = plan
+
+        def make(kind, p, meta, cin2=0):
+            p = "model." + p
+            if kind == "conv_in":
+                return _conv(sd, p, dt, dev, meta[0])
+            if kind == "res":
+                cin, cout = meta[0] - cin2, meta[1]
+                emb = _linear(sd, p + ".emb_layers.1", torch.float32, dev)(silu_e)
+                ss = emb.t.view(-1)[: 2 * cout].clone()
+                names = (p + ".in_layers.0", p + ".in_layers.2", p + ".out_layers.0", p + ".out_layers.3",
+                         p + ".skip_connection")
+                return _ResBlock(sd, names, cin, cin2, cout, dt, dev, cfg.gn_groups, 1e-5,
+                                 scale=ss[:cout].contiguous(), shift=ss[cout:].contiguous())
+            if kind == "swin":
+                return _SwinLayer(sd, p, meta[0], cfg, dt, dev)
+            if kind in ("down", "up"):
+                return _conv(sd, p, dt, dev, meta[0])
+            raise ValueError(kind)
+
+        self.u_input, chans = [], []
+        for kind, p, meta in plan["input"]:
+            ops_ = meta if kind == "seq" else [(kind, p, meta)]
+            mods = [(k, make(k, pp, m)) for k, pp, m in ops_]
+            self.u_input.append(mods)
+            chans.append(ops_[-1][2][-1] if ops_[-1][0] != "swin" else ops_[0][2][1])
+        self.u_middle = [(k, make(k, pp, m)) for k, pp, m in plan["middle"]]
+        self.u_output = []
+        for kind, p, meta in plan["output"]:
+            ich = chans.pop()
+            mods = []
+            for j, (k, pp, m) in enumerate(meta):
+                mods.append((k, make(k, pp, m, cin2=ich if j == 0 else 0)))
+            self.u_output.append(mods)
+        self.u_out_norm = _GN(sd, "model.out.0", dev)
+        self.u_out_conv = _conv(sd, "model.out.2", dt, dev, plan["out_ch"])
+
+    def _build_ae(self, sd):
+        cfg, dev, dt = self.cfg, self.device, self.dtype
+        ch, mults, nrb, g = cfg.ae_ch, cfg.ae_ch_mult, cfg.ae_num_res_blocks, cfg.gn_groups
+
+        def rb(p, cin, cout):
+            names = (p + ".norm1", p + ".conv1", p + ".norm2", p + ".conv2", p + ".nin_shortcut")
+            return _ResBlock(sd, names, cin, 0, cout, dt, dev, g, 1e-6)
+
+        self.e_conv_in = _conv(sd, "ae.encoder.conv_in", dt, dev, 3)
+        self.e_down = []
+        cin = ch
+        for lvl, m in enumerate(mults):
+            blocks = []
+            for b in range(nrb):
+                blocks.append(rb(f"ae.encoder.down.{lvl}.block.{b}", cin, ch * m))
+                cin = ch * m
+            ds = _conv(sd, f"ae.encoder.down.{lvl}.downsample.conv", dt, dev, cin) if lvl != len(mults) - 1 else None
+            self.e_down.append((blocks, ds))
+        self.e_mid = [rb("ae.encoder.mid.block_1", cin, cin), rb("ae.encoder.mid.block_2", cin, cin)]
+        self.e_norm_out = _GN(sd, "ae.encoder.norm_out", dev)
+        self.e_conv_out = _conv(sd, "ae.encoder.conv_out", dt, dev, cin)
+        self.quant_conv = _conv(sd, "ae.quant_conv", dt, dev, cfg.z_channels)
+        self.post_quant_conv = _conv(sd, "ae.post_quant_conv", dt, dev, cfg.embed_dim)
+        cin = ch * mults[-1]
+        self.d_conv_in = _conv(sd, "ae.decoder.conv_in", dt, dev, cfg.z_channels)
+        self.d_mid = [rb("ae.decoder.mid.block_1", cin, cin), rb("ae.decoder.mid.block_2", cin, cin)]
+        self.d_up = []
+        for lvl in reversed(range(len(mults))):
+            blocks = []
+            for b in range(nrb + 1):
+                blocks.append(rb(f"ae.decoder.up.{lvl}.block.{b}", cin, ch * mults[lvl]))
+                cin = ch * mults[lvl]
+            us = _conv(sd, f"ae.decoder.up.{lvl}.upsample.conv", dt, dev, cin) if lvl != 0 else None
+            self.d_up.append((blocks, us))
+        self.d_norm_out = _GN(sd, "ae.decoder.norm_out", dev)
+        self.d_conv_out = _conv(sd, "ae.decoder.conv_out", dt, dev, cin)
+
+    # ------------------------------------------------------------------ stages
+    def _gn_silu_conv(self, x: Act, norm: _GN, conv: PackedConv, eps: float) -> Act:
+        pa, pb = ops.groupnorm_affine([x], norm.gamma, norm.beta, self.cfg.gn_groups, eps)
+        if self.fuse_gn:
+            return conv(x, prologue=(pa, pb))
+        ops.affine_act(x, pa, pb, act=2, out=x)
+        return conv(x)
+
+    def unet(self, x: Act) -> Act:
+        def run(mods, h, h2=None):
+            for j, (kind, m) in enumerate(mods):
+                if kind == "res":
+                    h = m(h, h2 if j == 0 else None, fuse_gn=self.fuse_gn)
+                elif kind == "swin":
+                    h = m(h)
+                elif kind == "down":
+                    h = m(h, stride=2)
+                elif kind == "up":
+                    h = m(h, upsample=True)
+                else:
+                    h = m(h)
+            return h
+
+        hs: List[Act] = []
+        h = x
+        for mods in self.u_input:
+            h = run(mods, h)
+            hs.append(h)
+        h = run(self.u_middle, h)
+        for mods in self.u_output:
+            h = run(mods, h, hs.pop())
+        return self._gn_silu_conv(h, self.u_out_norm, self.u_out_conv, 1e-5)
+
+    def encode(self, x: Act) -> Act:
+        h = self.e_conv_in(x)
+        for blocks, ds in self.e_down:
+            for b in blocks:
+                h = b(h, fuse_gn=self.fuse_gn)
+            if ds is not None:
+                h = ds(h, stride=2, pad=0, ho=h.h // 2, wo=h.w // 2)
+        for b in self.e_mid:
+            h = b(h, fuse_gn=self.fuse_gn)
+        h = self._gn_silu_conv(h, self.e_norm_out, self.e_conv_out, 1e-6)
+        return self.quant_conv(h)
+
+    def decode(self, z: Act, quantize: Optional[bool] = None, want_idx=False):
+        idx = None
+        if self.cfg.quantize if quantize is None else quantize:
+            z, idx = ops.vq_nearest(z, self.codebook, want_idx=True)
+        h = self.d_conv_in(self.post_quant_conv(z))
+        for b in self.d_mid:
+            h = b(h, fuse_gn=self.fuse_gn)
+        for blocks, us in self.d_up:
+            for b in blocks:
+                h = b(h, fuse_gn=self.fuse_gn)
+            if us is not None:
+                h = us(h, upsample=True)
+        out = self._gn_silu_conv(h, self.d_norm_out, self.d_conv_out, 1e-6)
+        return (out, idx) if want_idx else out
+
+    def padded_latent_shape(self, h, w):
+        a = self.cfg.unet_align
+        return (math.ceil(h / a) * a, math.ceil(w / a) * a)
+
+    def forward(self, lr_u8: torch.Tensor, noise: torch.Tensor, *, swap_rb=False, want_f32=False,
+                stages: Optional[dict] = None):
+        """lr_u8: [n,h,w,3] u8 on the device.  noise: [n,latent_ch,Hp,Wp] f32 on the device.
+        Returns [n,4h,4w,3] u8 (and the pre-quantisation f32 image in [0,1] if want_f32)."""
+        cfg = self.cfg
+        n, h, w, _ = lr_u8.shape
+        hp, wp = self.padded_latent_shape(h, w)
+        if tuple(noise.shape) != (n, cfg.latent_ch, hp, wp):
+            raise ValueError(f"noise must be {(n, cfg.latent_ch, hp, wp)}, got {tuple(noise.shape)}")
+        y = ops.u8_to_float(lr_u8, self.dtype, 2.0, -1.0, swap_rb=swap_rb, div255=True)
+        y_up = ops.bicubic_upsample(y, cfg.sf)
+        z_y = self.encode(y_up)
+        if stages is not None:
+            stages["y_up"], stages["z_y"] = y_up, z_y
+        del y_up
+        std = math.sqrt(cfg.etas_end * cfg.kappa ** 2 + 1.0)
+        uin = ops.new_act(n, hp, wp, 2 * cfg.latent_ch, self.dtype, self.device, zero=True)
+        ops.pad_reflect_axpy(z_y, hp, wp, uin, 0, mul=1.0 / std, add=noise.contiguous(),
+                             add_mul=cfg.kappa * math.sqrt(cfg.etas_end) / std)
+        ops.pad_reflect_axpy(y, hp, wp, uin, cfg.latent_ch, mul=1.0)
+        z0 = self.unet(uin)
+        if hp != h or wp != w:
+            z0 = ops.crop_copy(z0, h, w)
+        if stages is not None:
+            stages["z0"] = z0
+        dec = self.decode(z0)
+        if stages is not None:
+            stages["dec"] = dec
+        return ops.float_to_u8(dec, 0.5, 0.5, mode=0, swap_rb=swap_rb, want_f32=want_f32)
+
+    def make_noise(self, seed: int, frame_indices, h: int, w: int) -> torch.Tensor:
+        hp, wp = self.padded_latent_shape(h, w)
+        ns = [frame_noise(self.cfg, seed, fi, hp, wp) for fi in frame_indices]
+        return torch.cat(ns, 0).to(self.device, non_blocking=True)

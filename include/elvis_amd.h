@@ -1,0 +1,199 @@
+/*
+ * elvis_amd.h - C ABI of the MI355X-native ELVIS client-side restoration hot path.
+ *
+ * The reference (emanuele-artioli/elvis) is pure Python and has NO FFI of its own
+ * (SURVEY.md F2, section 8b): its drop-in boundary is three Python callable protocols
+ * (P1 upsample_fn, P2 process_fn, P3 restore_fn) plus the sharding helpers.  This header
+ * is the C-ABI that the Python shim in `elvis_amd/` calls through ctypes to implement
+ * those protocols; each entry point cites the reference code whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative ELVIS_E_* code on failure; the
+ *    message for the calling thread is available from elvis_last_error().
+ *  - all pointers are DEVICE pointers (HBM) unless the name ends in `_host`.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - no entry point allocates, frees or synchronises: callers own all buffers
+ *    (hipGraph-capturable, cdna guide G9).
+ *  - images are NHWC, C-contiguous.  u8 frames are (n,h,w,3).  Float tensors carry an
+ *    explicit channel pitch (`*_pitch`, in elements, multiple of 8) so producers can write
+ *    straight into channel slices of a wider buffer.
+ *  - dtype codes: ELVIS_F32 = 0 (exact-parity mode), ELVIS_F16 = 1 (MFMA fast mode,
+ *    fp32 accumulate).
+ */
+#ifndef ELVIS_AMD_H
+#define ELVIS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELVIS_ABI_VERSION 1
+
+#define ELVIS_OK 0
+#define ELVIS_E_INVALID (-1)   /* bad shape / argument  -> Python ValueError   */
+#define ELVIS_E_RUNTIME (-2)   /* HIP launch failure    -> Python RuntimeError */
+#define ELVIS_E_UNSUPPORTED (-3)
+
+#define ELVIS_F32 0
+#define ELVIS_F16 1
+
+#define ELVIS_ROUND_CV2 0      /* 2x2: (s+2)>>2 ; else rint(float(s)*(1.f/area)) half-even */
+#define ELVIS_ROUND_HALF_UP 1  /* (s + area/2) / area */
+
+typedef void* elvis_stream_t;
+
+int elvis_abi_version(void);
+const char* elvis_last_error(void);
+
+/* ------------------------------------------------------------------ block-map glue (u8) */
+
+/* out[blk(i,j)] = (map[n,i,j] <= thr) ? a : b, per b x b block; pixels outside the
+ * by*block x bx*block grid take `b`.  Replaces the python By x Bx paste loop of
+ * upscale_realesrgan_adaptive (elvis.py:2584-2595) and the boolean-mask block copy of
+ * _instantir_chunk_worker (elvis.py:2975-2978).  If map_out != NULL it receives the clamped
+ * map of elvis.py:2592: map_out = (map <= thr) ? map : clamp_to. */
+int elvis_recompose_u8(const uint8_t* a, const uint8_t* b, const int32_t* map, uint8_t* out,
+                       int32_t* map_out, int n, int h, int w, int c, int block, int by, int bx,
+                       int thr, int clamp_to, elvis_stream_t stream);
+
+/* Integer-factor box-mean downscale; replaces cv2.resize(..., INTER_AREA) at
+ * elvis.py:2565 and elvis.py:2581.  h,w must be divisible by factor. */
+int elvis_area_downscale_u8(const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                            int factor, int rounding, elvis_stream_t stream);
+
+/* out = trunc(clip(orig*(1-alpha*m) + rest*(alpha*m), 0, 255)), m = (map>0) upsampled by
+ * `block` (nearest).  Replaces blended_restoration's per-frame fp32 blend (utils.py:1581-1599). */
+int elvis_blend_u8(const uint8_t* orig, const uint8_t* rest, const int32_t* map, uint8_t* out,
+                   int n, int h, int w, int c, int block, int by, int bx, float alpha,
+                   elvis_stream_t stream);
+
+/* Per-level select: out block (i,j) of frame f = versions[level_slot[map[f,i,j]]][f] block;
+ * pixels outside the floored grid are 0.  `versions` is a DEVICE array of n_versions device
+ * pointers, each (n,h,w,c) u8; `slot_of_level` is a DEVICE int32 table of size n_levels.
+ * Replaces the F x By x Bx python loop of restore_video_adaptively (presley.py:1262-1273). */
+int elvis_select_levels_u8(const uint8_t* const* versions, const int32_t* slot_of_level, int n_levels,
+                           const int32_t* map, uint8_t* out, int n, int h, int w, int c, int block,
+                           int by, int bx, elvis_stream_t stream);
+
+/* Feathered tile accumulate, bit-exact with numpy's float32 evaluation order:
+ *   sw = f32(f64(f32(f64(wy[y]) * wx[x])) * wx2[x]); wgt = sw * temporal_weight;
+ *   acc[y0+y, x0+x, :] += f32(tile) * wgt;  wsum[y0+y, x0+x] += wgt.
+ * wy (th floats) holds the top/bottom ramps already applied in float32, wx / wx2 (tw doubles)
+ * the left / right np.linspace ramps (1.0 where no ramp).  Replaces resource_aware_restore's
+ * blend loop (utils.py:275-314).  acc is (h,w,c) f32, wsum (h,w) f32, tile (th,tw,c) u8. */
+int elvis_tile_accumulate_f32(float* acc, float* wsum, const uint8_t* tile, const float* wy,
+                              const double* wx, const double* wx2, int h, int w, int y0, int x0, int th,
+                              int tw, int c, float temporal_weight, elvis_stream_t stream);
+
+/* out = trunc(clip(acc / (wsum>0 ? wsum : 1), 0, 255)) (utils.py:317-324). */
+int elvis_tile_normalize_u8(const float* acc, const float* wsum, uint8_t* out, int h, int w, int c,
+                            elvis_stream_t stream);
+
+/* Integer-exact sum of squared u8 differences per frame, for PSNR/MSE (elvis.py:627-671,
+ * presley.py:226-245).  mask (n,h,w) u8 may be NULL.  sse_out / cnt_out: n u64 each (sum, number
+ * of compared elements); both must be zeroed by the caller. */
+int elvis_sse_u8(const uint8_t* a, const uint8_t* b, const uint8_t* mask, unsigned long long* sse_out,
+                 unsigned long long* cnt_out, int n, int h, int w, int c, elvis_stream_t stream);
+
+/* ------------------------------------------------------------------ u8 <-> float */
+
+/* dst[n,h,w,pitch] = (div255 ? src_u8/255 : src_u8) * scale + bias for the first 3 channels
+ * (optionally swapping R and B), zero for the pad channels.  Replaces the cvtColor/PIL//255 conversions of
+ * elvis.py:2959-2960 and RealESRGANer.enhance's pre-processing (elvis.py:2515). */
+int elvis_u8_to_float(const uint8_t* src, void* dst, int dtype, int n, int h, int w, int pitch,
+                      float scale, float bias, int swap_rb, int div255, elvis_stream_t stream);
+
+/* t = clip(src*scale + bias, 0, 1); dst_u8 = cast(t*255); mode 0 = round-half-even, 1 = truncate
+ * (utils.py:324).  Optionally also writes the pre-quantisation t as f32 (n,h,w,3) to `f32_out`
+ * (may be NULL) for the max-abs parity report. */
+int elvis_float_to_u8(const void* src, int dtype, uint8_t* dst, float* f32_out, int n, int h, int w,
+                      int pitch, float scale, float bias, int mode, int swap_rb, elvis_stream_t stream);
+
+/* ------------------------------------------------------------------ model kernels */
+
+typedef struct elvis_conv_desc {
+    int dtype;          /* ELVIS_F32 / ELVIS_F16 (activations, weights; fp32 accumulate)      */
+    int n, h, w;        /* INPUT spatial size (before the optional nearest 2x upsample)        */
+    int cin, cin_pitch; /* channels of input 1 and its pitch                                   */
+    int cin2, cin2_pitch; /* optional second input (virtual channel concat), 0 if unused       */
+    int cout, cout_pitch; /* logical output channels, output pitch                             */
+    int ksize;          /* 1 or 3                                                              */
+    int stride;         /* 1 or 2                                                              */
+    int pad_before;     /* zero padding before (top/left); after is implied by ho/wo           */
+    int upsample;       /* 1: input is nearest-upsampled 2x before the conv                    */
+    int ho, wo;         /* output spatial size                                                 */
+    int act;            /* epilogue activation: 0 none, 1 GELU(erf), 2 SiLU                    */
+    int prologue;       /* 0 none, 1: x <- silu(x*pa[n,c]+pb[n,c]) on load (fused GroupNorm)   */
+} elvis_conv_desc;
+
+/* Number of bytes of the packed weight buffer for a conv (depends on cin/cin2/cout/ksize/dtype). */
+size_t elvis_conv_packed_weight_bytes(const elvis_conv_desc* d);
+
+/* Pack PyTorch OIHW fp32 weights (host or device pointer given by `w_oihw_device`) into the
+ * kernel's [tap][kchunk][cout_pad][kvec] layout, converting to `dtype`. */
+int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_oihw, void* packed,
+                            elvis_stream_t stream);
+
+/* y = act(conv(x [,x2]) + bias) + residual.  Implicit-GEMM on MFMA.  `bias` f32[cout] or NULL,
+ * `residual` same dtype/pitch as out or NULL, `pa`,`pb` f32[n, cin+cin2] for the prologue.
+ * This is the slot where the reference calls RealESRGANer.enhance (elvis.py:2515) /
+ * restore_images_batch (elvis.py:2963-2970): the conv/linear layers of the restorer. */
+int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const void* w_packed,
+                 const float* bias, const void* residual, int residual_pitch, const float* pa,
+                 const float* pb, void* out, elvis_stream_t stream);
+
+/* GroupNorm statistics: per-(n,channel) sum and sum of squares, sums[n, sums_ctot, 2] f64
+ * (f32 partials per workgroup, one f64 atomic per channel per workgroup).  The tensor's channels
+ * land at [sums_coff, sums_coff+c) so a virtual concat of two tensors shares one buffer.
+ * `sums` must be zeroed by the caller. */
+int elvis_groupnorm_sums(const void* x, int dtype, int n, int hw, int c, int pitch, double* sums,
+                         int sums_ctot, int sums_coff, elvis_stream_t stream);
+
+/* Turn sums into per-(n,channel) affine pa,pb so that GN(x)*(1+scale)+shift == x*pa+pb.
+ * gamma,beta f32[c]; scale,shift f32[c] may be NULL (then 0). */
+int elvis_groupnorm_affine(const double* sums, const float* gamma, const float* beta, const float* scale,
+                           const float* shift, float* pa, float* pb, int n, int hw, int c, int groups,
+                           float eps, elvis_stream_t stream);
+
+/* y = act(x*pa[n,c] + pb[n,c]); act 0 none / 2 SiLU.  In-place allowed. */
+int elvis_affine_act(const void* x, void* y, int dtype, int n, int hw, int c, int pitch_in,
+                     int pitch_out, const float* pa, const float* pb, int act, elvis_stream_t stream);
+
+/* LayerNorm over the channel dim of each token. */
+int elvis_layernorm(const void* x, void* y, int dtype, long long tokens, int c, int pitch_in,
+                    int pitch_out, const float* gamma, const float* beta, float eps, elvis_stream_t stream);
+
+/* Swin (shifted-)window attention on a token image qkv[n,h,w,3*E] (q|k|v, head-major inside
+ * each), window ws, `shift` cyclic shift (0 or ws/2) with the standard region mask, relative
+ * position bias table [(2ws-1)^2, heads] f32.  out[n,h,w,E] in image order (un-shifted). */
+int elvis_window_attention(const void* qkv, void* out, int dtype, int n, int h, int w, int heads,
+                           int head_dim, int ws, int shift, int qkv_pitch, int out_pitch,
+                           const float* bias_table, float scale, elvis_stream_t stream);
+
+/* PyTorch bicubic (A=-0.75, align_corners=False) x`sf` upsample of a float NHWC image. */
+int elvis_bicubic_upsample(const void* x, void* y, int dtype, int n, int h, int w, int c, int pitch_in,
+                           int pitch_out, int sf, elvis_stream_t stream);
+
+/* Nearest-codebook lookup: zq = codebook[argmin_k sum_c (z_c - e_kc)^2] (first index wins). */
+int elvis_vq_nearest(const void* z, void* zq, int32_t* idx_out, int dtype, long long pixels, int c,
+                     int pitch_in, int pitch_out, const float* codebook, int n_embed, elvis_stream_t stream);
+
+/* Reflect-pad (right/bottom) copy of a float NHWC image into a larger one, optionally into a
+ * channel slice, with y = x*mul + add_mul*add[...] (used for x_T = z_y + kappa*sqrt(eta)*eps
+ * and the 1/sqrt(eta*kappa^2+1) input scaling; `add` is f32 NCHW noise or NULL). */
+int elvis_pad_reflect_axpy(const void* x, void* y, int dtype, int n, int h, int w, int c, int pitch_in,
+                           int hp, int wp, int pitch_out, int ch_offset_out, float mul, const float* add,
+                           float add_mul, elvis_stream_t stream);
+
+/* y[n,h,w,:c] = x[n,:h,:w,:c] crop-copy between pitched tensors (dtype-preserving). */
+int elvis_crop_copy(const void* x, void* y, int dtype, int n, int h_in, int w_in, int pitch_in, int h,
+                    int w, int c, int pitch_out, elvis_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELVIS_AMD_H */

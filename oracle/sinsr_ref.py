@@ -178,12 +178,21 @@ def ae_encode(sd: SD, cfg: SinSRConfig, x):
 
 
 def vq_quantize(sd: SD, z):
-    """nearest codebook entry (argmin of squared distance; first index wins ties)."""
+    """Nearest codebook entry: argmin_k sum_c (z_c - e_kc)^2 evaluated as ((d0*d0)+d1*d1)+d2*d2 in
+    plain fp32 (no FMA contraction), first index wins ties - the same evaluation order as the HIP
+    kernel, so identical inputs give identical codes."""
     cb = sd["ae.quantize.embedding.weight"]
     b, c, h, w = z.shape
     zf = z.permute(0, 2, 3, 1).reshape(-1, c)
-    d = (zf * zf).sum(1, keepdim=True) - 2 * zf @ cb.t() + (cb * cb).sum(1)[None]
-    idx = d.argmin(1)
+    idx = torch.empty(zf.shape[0], dtype=torch.long)
+    for s0 in range(0, zf.shape[0], 4096):
+        zc = zf[s0:s0 + 4096]
+        d = None
+        for k in range(c):
+            df = zc[:, k:k + 1] - cb[None, :, k]
+            sq = df * df
+            d = sq if d is None else d + sq
+        idx[s0:s0 + 4096] = d.argmin(1)
     return cb[idx].view(b, h, w, c).permute(0, 3, 1, 2).contiguous(), idx.view(b, h, w)
 
 

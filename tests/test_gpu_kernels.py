@@ -1,0 +1,220 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against PyTorch-CPU fp32
+restatements of the same op.  Tolerances: fp32 mode 1e-4 abs on O(1) activations (the path bar is
+1e-3 max-abs end to end, BASELINE.json); f16 mode 2e-2 (f16 inputs/weights, fp32 accumulate)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _act(x_nchw, dtype, dev):
+    from elvis_amd import ops
+    n, c, h, w = x_nchw.shape
+    a = ops.new_act(n, h, w, c, dtype, dev, zero=True)
+    a.t[..., :c] = x_nchw.permute(0, 2, 3, 1).to(dev, dtype)
+    return a
+
+
+def _nchw(a):
+    return a.t[..., :a.c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+TOL = {torch.float32: 2e-4, torch.float16: 3e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, k, stride, pad, upsample, h, w
+    (32, 64, 3, 1, 1, False, 17, 23),
+    (3, 128, 3, 1, 1, False, 16, 16),
+    (128, 3, 3, 1, 1, False, 19, 21),
+    (160, 160, 3, 1, 1, False, 16, 24),
+    (64, 64, 3, 2, 1, False, 16, 16),
+    (64, 64, 3, 2, 0, False, 16, 18),     # AE downsample: pad (0,1,0,1)
+    (64, 32, 3, 1, 1, True, 9, 11),       # nearest-2x fused
+    (192, 576, 1, 1, 0, False, 8, 16),    # linear
+    (48, 200, 1, 1, 0, False, 5, 7),
+])
+def test_conv(gpu_device, dtype, cfg):
+    from elvis_amd import ops
+    cin, cout, k, stride, pad, ups, h, w = cfg
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = ops.PackedConv(wt, b, dtype, gpu_device, cin)
+    xa = _act(x, dtype, gpu_device)
+    xr = x.to(dtype).float()
+    wr = wt.to(dtype).float()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if stride == 2 and pad == 0:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, b, stride=2)
+        y = conv(xa, stride=2, pad=0, ho=h // 2, wo=w // 2)
+    else:
+        ref = F.conv2d(xr, wr, b, stride=stride, padding=pad)
+        y = conv(xa, stride=stride, pad=pad, upsample=ups)
+    got = _nchw(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_conv_concat_residual_act_prologue(gpu_device, dtype):
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    c1, c2, cout, h, w = 64, 32, 96, 12, 20
+    x1, x2 = torch.randn(1, c1, h, w, generator=g), torch.randn(1, c2, h, w, generator=g)
+    wt = torch.randn(cout, c1 + c2, 3, 3, generator=g) / math.sqrt((c1 + c2) * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(1, cout, h, w, generator=g)
+    pa = torch.rand(1, c1 + c2, generator=g) + 0.5
+    pb = torch.randn(1, c1 + c2, generator=g) * 0.2
+    conv = ops.PackedConv(wt, b, dtype, gpu_device, c1, c2)
+    a1, a2, ar = _act(x1, dtype, gpu_device), _act(x2, dtype, gpu_device), _act(res, dtype, gpu_device)
+    xcat = torch.cat([x1, x2], 1).to(dtype).float()
+    wr = wt.to(dtype).float()
+    # concat + gelu + residual
+    y = conv(a1, a2, act=1, residual=ar)
+    ref = F.gelu(F.conv2d(xcat, wr, b, padding=1)) + res.to(dtype).float()
+    assert (_nchw(y) - ref).abs().max().item() < TOL[dtype]
+    # fused GroupNorm-affine + SiLU prologue
+    y = conv(a1, a2, prologue=(pa.to(gpu_device), pb.to(gpu_device)))
+    xin = F.silu(xcat * pa[:, :, None, None] + pb[:, :, None, None])
+    if dtype == torch.float16:
+        xin = xin.half().float()
+    ref = F.conv2d(xin, wr, b, padding=1)
+    assert (_nchw(y) - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("c,groups", [(64, 32), (160, 32), (96, 8)])
+def test_groupnorm_silu(gpu_device, dtype, c, groups):
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, c, 21, 19, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    scale, shift = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3
+    xa = _act(x, dtype, gpu_device)
+    dv = lambda t: t.to(gpu_device)
+    pa, pb = ops.groupnorm_affine([xa], dv(gamma), dv(beta), groups, 1e-5, scale=dv(scale), shift=dv(shift))
+    y = ops.affine_act(xa, pa, pb, act=2)
+    xr = x.to(dtype).float()
+    ref = F.silu(F.group_norm(xr, groups, gamma, beta, 1e-5) * (1 + scale[None, :, None, None]) + shift[None, :, None, None])
+    assert (_nchw(y) - ref).abs().max().item() < (5e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_groupnorm_virtual_concat(gpu_device):
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x1, x2 = torch.randn(1, 64, 8, 8, generator=g), torch.randn(1, 32, 8, 8, generator=g) * 2
+    gamma, beta = torch.randn(96, generator=g), torch.randn(96, generator=g)
+    a1, a2 = _act(x1, torch.float32, gpu_device), _act(x2, torch.float32, gpu_device)
+    pa, pb = ops.groupnorm_affine([a1, a2], gamma.to(gpu_device), beta.to(gpu_device), 32, 1e-6)
+    xc = torch.cat([x1, x2], 1)
+    ref = F.group_norm(xc, 32, gamma, beta, 1e-6)
+    got = xc * pa.cpu()[:, :, None, None] + pb.cpu()[:, :, None, None]
+    assert (got - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("c", [192, 64])
+def test_layernorm(gpu_device, dtype, c):
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, c, 9, 13, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    xa = _act(x, dtype, gpu_device)
+    y = ops.layernorm(xa, gamma.to(gpu_device), beta.to(gpu_device), 1e-5)
+    ref = F.layer_norm(x.to(dtype).float().permute(0, 2, 3, 1), (c,), gamma, beta, 1e-5).permute(0, 3, 1, 2)
+    assert (_nchw(y) - ref).abs().max().item() < (5e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shift", [0, 4])
+def test_window_attention(gpu_device, dtype, shift):
+    from elvis_amd import ops
+    from elvis_amd.weights import relative_position_index
+    from oracle import sinsr_ref as R
+    g = torch.Generator().manual_seed(6)
+    heads, hd, ws, h, w = 3, 32, 8, 16, 24
+    E = heads * hd
+    qkv = torch.randn(1, 3 * E, h, w, generator=g)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    qa = _act(qkv, dtype, gpu_device)
+    out = ops.window_attention(qa, heads, hd, ws, shift, table.to(gpu_device), hd ** -0.5)
+    # torch reference (same math as oracle.sinsr_ref.swin_block's attention core)
+    t = qkv.to(dtype).float().permute(0, 2, 3, 1)
+    if shift:
+        t = torch.roll(t, (-shift, -shift), (1, 2))
+    win = R.window_partition(t, ws)
+    nw, n = win.shape[0], ws * ws
+    q, k, v = win.view(nw, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    bias = table[relative_position_index(ws).view(-1)].view(n, n, heads).permute(2, 0, 1)
+    attn = attn + bias[None]
+    if shift:
+        m = R.shift_mask(h, w, ws, shift)
+        attn = (attn.view(1, m.shape[0], heads, n, n) + m[None, :, None]).view(-1, heads, n, n)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(nw, n, E)
+    o = R.window_reverse(o, ws, h, w)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    ref = o.permute(0, 3, 1, 2)
+    assert (_nchw(out) - ref).abs().max().item() < (5e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_bicubic(gpu_device, dtype):
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(2, 3, 13, 17, generator=g) * 2 - 1
+    y = ops.bicubic_upsample(_act(x, dtype, gpu_device), 4)
+    ref = F.interpolate(x.to(dtype).float(), scale_factor=4, mode="bicubic", align_corners=False)
+    assert (_nchw(y) - ref).abs().max().item() < (2e-5 if dtype == torch.float32 else 3e-3)
+
+
+def test_vq_nearest_exact(gpu_device):
+    from elvis_amd import ops
+    from oracle import sinsr_ref as R
+    g = torch.Generator().manual_seed(8)
+    cb = torch.rand(3000, 3, generator=g) * 3 - 1.5
+    z = torch.randn(1, 3, 30, 41, generator=g)
+    z[0, :, 0, 0] = cb[17]          # exact hit
+    zq, idx = ops.vq_nearest(_act(z, torch.float32, gpu_device), cb.to(gpu_device), want_idx=True)
+    ref_q, ref_idx = R.vq_quantize({"ae.quantize.embedding.weight": cb}, z)
+    assert torch.equal(idx.cpu().long(), ref_idx)
+    assert torch.equal(_nchw(zq), ref_q)
+
+
+def test_pad_reflect_axpy_and_crop(gpu_device):
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 3, 10, 13, generator=g)
+    noise = torch.randn(1, 3, 16, 16, generator=g)
+    out = ops.new_act(1, 16, 16, 6, torch.float32, gpu_device, zero=True)
+    xa = _act(x, torch.float32, gpu_device)
+    ops.pad_reflect_axpy(xa, 16, 16, out, 0, mul=0.5, add=noise.to(gpu_device), add_mul=2.0)
+    ops.pad_reflect_axpy(xa, 16, 16, out, 3, mul=1.0)
+    xp = F.pad(x, (0, 3, 0, 6), mode="reflect")
+    ref = torch.cat([xp * 0.5 + 2.0 * noise, xp], 1)
+    assert (_nchw(out) - ref).abs().max().item() < 1e-6
+    assert float(out.t[..., 6:].abs().max()) == 0.0
+    c = ops.crop_copy(out, 10, 13)
+    assert torch.equal(_nchw(c), _nchw(out)[:, :, :10, :13])
+
+
+def test_u8_float_roundtrip(gpu_device):
+    from elvis_amd import ops
+    rng = np.random.default_rng(0)
+    img = torch.from_numpy(rng.integers(0, 256, size=(2, 9, 11, 3), dtype=np.uint8)).to(gpu_device)
+    a = ops.u8_to_float(img, torch.float32, 2.0, -1.0, swap_rb=True, div255=True)
+    ref = (img.cpu().float().flip(-1) / 255.0) * 2.0 - 1.0
+    assert torch.equal(a.t[..., :3].cpu(), ref)
+    assert float(a.t[..., 3:].abs().max()) == 0.0
+    back, f32 = ops.float_to_u8(a, 0.5, 0.5, mode=0, swap_rb=True, want_f32=True)
+    assert torch.equal(back.cpu(), img.cpu())

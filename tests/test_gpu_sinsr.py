@@ -1,0 +1,143 @@
+"""End-to-end GPU parity of the SinSR-style 4x path against the PyTorch-CPU oracle on identical
+degraded inputs, weights (seed 0) and sampler noise (seed 42).
+
+Bars (BASELINE.json): fp32 mode <= 1e-3 max-abs on the pre-quantisation image in [0,1], PSNR
+within 0.01 dB; f16 mode is reported against looser documented bars.  The VQ nearest-code step is
+discontinuous, so the strict bar is asserted on the continuous path (quantize=False) and stage-wise
+(z0 before the lookup; decoder fed identical codes), and the quantised end-to-end run is held to a
+code-agreement + PSNR bar."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg, h, w, dtype, dev, seed=0):
+    from elvis_amd.sinsr import SinSRModel
+    from elvis_amd.weights import frame_noise, make_sinsr_weights
+    from oracle import sinsr_ref as R
+    sd = make_sinsr_weights(cfg, seed)
+    model = SinSRModel(cfg, sd, dev, dtype)
+    rng = np.random.default_rng(20260501)
+    # smooth-ish synthetic LR content
+    base = rng.random((h // 4 + 2, w // 4 + 2, 3)).astype(np.float32)
+    lr = np.kron(base, np.ones((4, 4, 1), np.float32))[:h, :w]
+    lr = np.clip(lr + rng.normal(0, 0.03, lr.shape), 0, 1)
+    lr_u8 = torch.from_numpy(np.round(lr * 255).astype(np.uint8))
+    hp, wp = R.padded_latent_shape(cfg, h, w)
+    noise = frame_noise(cfg, 42, 0, hp, wp)
+    return sd, model, lr_u8, noise
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float32) - b.astype(np.float32)) ** 2)
+    return float("inf") if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.parametrize("hw", [(24, 40), (64, 64)])
+def test_tiny_fp32_continuous_strict(gpu_device, hw):
+    from elvis_amd.weights import tiny_config
+    from oracle import sinsr_ref as R
+    cfg = dataclasses.replace(tiny_config(), quantize=False)
+    sd, model, lr, noise = _setup(cfg, hw[0], hw[1], torch.float32, gpu_device)
+    stages = {}
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True, stages=stages)
+    ref, rst = R.sinsr_forward(sd, cfg, lr, noise, return_stages=True)
+    for name in ("y_up", "z_y", "z0", "dec"):
+        a = stages[name]
+        got = a.t[0, :, :, :a.c].float().cpu().permute(2, 0, 1)
+        assert (got - rst[name][0]).abs().max().item() < 1e-3, name
+    assert (f32[0].cpu() - ref).abs().max().item() < 1e-3
+    ref_u8 = R.to_u8(ref).numpy()
+    got_u8 = u8[0].cpu().numpy()
+    assert np.abs(got_u8.astype(int) - ref_u8.astype(int)).max() <= 1
+    assert _psnr(got_u8, ref_u8) > 60.0   # >> the 0.01 dB agreement bar
+
+
+def test_tiny_fp32_quantized(gpu_device):
+    from elvis_amd.weights import tiny_config
+    from oracle import sinsr_ref as R
+    cfg = tiny_config()
+    sd, model, lr, noise = _setup(cfg, 32, 48, torch.float32, gpu_device)
+    stages = {}
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True, stages=stages)
+    ref, rst = R.sinsr_forward(sd, cfg, lr, noise, return_stages=True)
+    z0 = stages["z0"]
+    got_z0 = z0.t[0, :, :, :3].float().cpu().permute(2, 0, 1)
+    assert (got_z0 - rst["z0"][0]).abs().max().item() < 1e-3
+    # decoder parity when fed the oracle's z0 (identical codes by construction)
+    from elvis_amd import ops
+    za = ops.new_act(1, 32, 48, 3, torch.float32, gpu_device, zero=True)
+    za.t[..., :3] = rst["z0"][0].permute(1, 2, 0).to(gpu_device)
+    dec, idx = model.decode(za, want_idx=True)
+    _, ref_idx = R.vq_quantize(sd, rst["z0"])
+    assert torch.equal(idx.cpu().long(), ref_idx)
+    got = dec.t[0, :, :, :3].cpu().permute(2, 0, 1)
+    assert (got - rst["dec"][0]).abs().max().item() < 1e-3
+    # end to end with the lookup in the loop: codes may flip where z0 sits on a cell boundary
+    agree = np.mean(np.abs(u8[0].cpu().numpy().astype(int) - R.to_u8(ref).numpy().astype(int)) <= 1)
+    assert agree > 0.995
+
+
+def test_tiny_f16_fast_mode(gpu_device):
+    from elvis_amd.weights import tiny_config
+    from oracle import sinsr_ref as R
+    cfg = dataclasses.replace(tiny_config(), quantize=False)
+    sd, model, lr, noise = _setup(cfg, 32, 48, torch.float16, gpu_device)
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)
+    ref = R.sinsr_forward(sd, cfg, lr, noise)
+    err = (f32[0].cpu() - ref).abs().max().item()
+    print("f16 max-abs", err)
+    assert err < 3e-2                      # documented f16 bar (fp32 bar is 1e-3)
+    assert _psnr(u8[0].cpu().numpy(), R.to_u8(ref).numpy()) > 40.0
+
+
+def test_fused_gn_prologue_matches_unfused(gpu_device):
+    from elvis_amd.sinsr import SinSRModel
+    from elvis_amd.weights import tiny_config
+    cfg = dataclasses.replace(tiny_config(), quantize=False)
+    sd, model, lr, noise = _setup(cfg, 24, 40, torch.float32, gpu_device)
+    fused = SinSRModel(cfg, sd, gpu_device, torch.float32, fuse_gn=True)
+    a = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)[1]
+    b = fused.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)[1]
+    assert (a - b).abs().max().item() < 1e-4
+
+
+def test_full_config_256_fp32(gpu_device):
+    """BASELINE config 1: one 256x256 frame (64x64 LR), full-width SinSR config, fp32 mode."""
+    from elvis_amd.weights import SinSRConfig
+    from oracle import sinsr_ref as R
+    cfg = dataclasses.replace(SinSRConfig(), quantize=False)
+    sd, model, lr, noise = _setup(cfg, 64, 64, torch.float32, gpu_device)
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = R.sinsr_forward(sd, cfg, lr, noise)
+    err = (f32[0].cpu() - ref).abs().max().item()
+    print("full-config fp32 max-abs", err)
+    assert err < 1e-3
+    assert np.abs(u8[0].cpu().numpy().astype(int) - R.to_u8(ref).numpy().astype(int)).max() <= 1
+
+
+def test_restore_frames_sinsr_surface(gpu_device):
+    """P2 drop-in: restore_frames_sinsr keeps level-0 blocks bit-identical to the decoded input and
+    is independent of how frames are chunked (noise keyed on the global frame index)."""
+    from elvis_amd import restore
+    from elvis_amd.weights import tiny_config
+    cfg = tiny_config()
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8) for _ in range(3)]
+    maps = rng.integers(0, 3, size=(3, 8, 12)).astype(np.int32)
+    maps[2] = 0
+    out = restore.restore_frames_sinsr(frames, maps, 8, gpu_device, cfg=cfg)
+    assert len(out) == 3 and out[0].shape == (64, 96, 3) and out[0].dtype == np.uint8
+    assert np.array_equal(out[2], frames[2])
+    keep = np.repeat(np.repeat(maps[0] == 0, 8, 0), 8, 1)
+    assert np.array_equal(out[0][keep], frames[0][keep])
+    # chunk independence
+    a = restore.restore_frames_sinsr(frames[:1], maps[:1], 8, gpu_device, cfg=cfg, first_frame_index=0)
+    b = restore.restore_frames_sinsr(frames[1:], maps[1:], 8, gpu_device, cfg=cfg, first_frame_index=1)
+    for x, y in zip(a + b, out):
+        assert np.array_equal(x, y)
