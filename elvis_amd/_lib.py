@@ -45,7 +45,9 @@ SIGNATURES = {
     "elvis_float_to_u8": [vp, i32, vp, vp, i32, i32, i32, i32, f32, f32, i32, i32, vp],
     "elvis_conv_packed_weight_bytes": [C.POINTER(ConvDesc)],
     "elvis_conv_pack_weights": [C.POINTER(ConvDesc), vp, vp, vp],
-    "elvis_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
+    "elvis_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp],
+    "elvis_conv_stats_tiles": [C.POINTER(ConvDesc)],
+    "elvis_gn_partials_to_sums": [vp, i32, i32, i32, vp, i32, i32, vp],
     "elvis_groupnorm_sums": [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp],
     "elvis_groupnorm_affine": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "elvis_affine_act": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],

@@ -9,15 +9,15 @@
 // 16-byte (f32) NHWC store per 16x16 sub-tile.
 //
 // Both dtypes use the same LDS image: rows of 64 bytes (32 halfs / 16 floats of K), grouped in
-// 16-row x 64-byte sub-tiles of 1 KiB, XOR-swizzled with byte ^= ((byte>>9)&1)<<5 (the
-// "st_16x32" swizzle of the CDNA4 guide) which makes every ds_read_b128 lane group hit 16
-// distinct 16-byte slots.  One ds_read_b128 per lane feeds
+// 16-row x 64-byte sub-tiles of 1 KiB, XOR-swizzled (chunk bit 1 ^= row bit 2) so that every
+// ds_read_b128 lane group hits 16 distinct 16-byte slots for any 16 consecutive rows.  One ds_read_b128 per lane feeds
 //   f16: one v_mfma_f32_16x16x32_f16   (lane (r,g) holds k = 8g..8g+7)
 //   f32: four v_mfma_f32_16x16x4_f32   (lane (r,g) holds k = 4g..4g+3; MFMA e uses element e, so
 //        the four instructions together cover the 16 k of the row - the k order is permuted
 //        identically for A and B, which leaves the sum unchanged).
 // f32 mode is exact IEEE fp32 FMA chains (parity mode); f16 mode accumulates in fp32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +42,9 @@ struct ConvArgs {
     long long M;          // n*ho*wo
     int n_co_tiles;
     long long n_px_tiles;
+    // halo kernel only
+    float* stats;         // [n*tiles_y*tiles_x][cout][2] partial (sum, sumsq) or null
+    int tiles_x, tiles_y;
 };
 
 template <typename T> struct Frag;
@@ -59,9 +62,10 @@ __device__ __forceinline__ void mma_tile(float4v& acc, const float4v& a, const f
 }
 
 __device__ __forceinline__ int lds_row_off(int row, int q) {
-    // byte offset of 16-byte chunk q of `row` in the swizzled image
-    int r = row & 15;
-    return (row >> 4) * 1024 + r * 64 + ((q ^ (((r >> 3) & 1) << 1)) << 4);
+    // byte offset of 16-byte chunk q of 64-byte `row` in the swizzled image: chunk bit 1 is XORed
+    // with row bit 2.  Conflict-free for ds_read_b128 of ANY 16 consecutive rows (brute-forced
+    // against the gfx950 lane-group table), which the halo kernel needs for its dx-shifted reads.
+    return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
 template <typename T> __device__ __forceinline__ uint4 prologue_apply(uint4 v, const float* pa, const float* pb);
@@ -279,16 +283,291 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 "halo" kernel - the hot kernel of the SinSR path.
+//
+// A workgroup (4 waves) owns an 8 x 32 pixel output tile x TCO output channels.  Per 64-byte
+// K chunk (32 halfs / 16 floats of input channels) the (8+2) x (32+2) input halo is staged ONCE
+// in LDS - with the fused GroupNorm-affine + SiLU prologue applied on the way in - and the nine
+// taps read dx/dy-shifted windows of it, so activation bytes cross L2->LDS 1.33x instead of 9x
+// and the prologue math runs 1.33x instead of 9x per element.  Weights stream through a 3-slot LDS
+// ring, one (tap, chunk) slice of TCO x 64 B per step, register-staged one step ahead.
+// Epilogue: bias / activation / residual, NHWC store, and per-tile GroupNorm partial sums
+// (sum, sum of squares per output channel) for the NEXT layer's normalisation - no atomics, the
+// partials are reduced by elvis_gn_partials_to_sums.
+template <typename T, int TCO>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
+    constexpr int TY = 8, TX = 32, HX = TX + 2, HY = TY + 2, HP = HX * HY;
+    constexpr int HCH = HP * 4;
+    constexpr int H_PER = (HCH + 255) / 256;
+    constexpr int HALO_BYTES = HP * 64;
+    constexpr int W_BYTES = TCO * 64;
+    constexpr int W_PER = W_BYTES / 16 / 256;
+    constexpr int NW_CO = TCO / 64, NW_PX = 4 / NW_CO;
+    constexpr int ROWS = TY / NW_PX;
+    constexpr int WPX = ROWS * 2, WCO = 4;
+    constexpr int VEC = DT<T>::VEC, KC = 4 * VEC;
+    typedef typename Frag<T>::type frag_t;
+    static_assert(W_PER >= 1, "weight slot must cover the workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;                     // 2 buffers of HALO_BYTES
+    char* const wring = smem + 2 * HALO_BYTES;   // 3 slots of W_BYTES
+
+    long long nblk = (long long)p.n_co_tiles * p.tiles_x * p.tiles_y * p.n;
+    long long bid = blockIdx.x;
+    {
+        long long q = nblk / 8, r = nblk % 8;
+        long long xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int co_tile = (int)(bid % p.n_co_tiles);
+    long long t = bid / p.n_co_tiles;
+    const int tx = (int)(t % p.tiles_x);
+    t /= p.tiles_x;
+    const int ty = (int)(t % p.tiles_y);
+    const int nimg = (int)(t / p.tiles_y);
+    const int oy0 = ty * TY, ox0 = tx * TX, co0 = co_tile * TCO;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w_co = wave / NW_PX, w_px = wave % NW_PX;
+    const int lh = p.upsample ? p.h * 2 : p.h, lw = p.upsample ? p.w_in * 2 : p.w_in;
+
+    // ---- halo staging plan: chunk = tid + 256*i -> (halo pixel, 16-byte channel slice q = tid&3)
+    int h_src[H_PER], h_lds[H_PER];
+#pragma unroll
+    for (int i = 0; i < H_PER; ++i) {
+        int chunk = tid + i * 256;
+        int pix = chunk >> 2;
+        int hy = pix / HX, hx = pix - hy * HX;
+        int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+        bool ok = chunk < HCH && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
+        int sy = p.upsample ? (gy >> 1) : gy, sx = p.upsample ? (gx >> 1) : gx;
+        h_src[i] = ok ? (nimg * p.h + sy) * p.w_in + sx : -1;
+        h_lds[i] = chunk < HCH ? lds_row_off(pix, chunk & 3) : -1;
+    }
+    const int q4 = tid & 3;
+    const int nkc = p.nkc;
+    const int nsteps = nkc * 9;
+
+    uint4 hreg[H_PER];
+    uint4 wreg[W_PER];
+
+    auto halo_load = [&](int kc) {
+        const bool second = kc >= p.nkc1;
+        const char* xsrc = (const char*)(second ? p.x2 : p.x);
+        const int pitch = second ? p.cin2_pitch : p.cin_pitch;
+        const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+        const bool ch_ok = c0 < pitch;
+#pragma unroll
+        for (int i = 0; i < H_PER; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (h_src[i] >= 0 && ch_ok)
+                v = *reinterpret_cast<const uint4*>(xsrc + ((long long)h_src[i] * pitch + c0) * (long long)sizeof(T));
+            hreg[i] = v;
+        }
+    };
+    auto halo_store = [&](int kc, int buf) {
+        if (p.prologue) {
+            const bool second = kc >= p.nkc1;
+            const int cvalid = second ? p.cin2 : p.cin;
+            const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+            const long long cb = (long long)nimg * (p.cin + p.cin2) + (second ? p.cin : 0) + c0;
+            float la[VEC], lb[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                bool in = (c0 + e) < cvalid;
+                la[e] = in ? p.pa[cb + e] : 0.0f;
+                lb[e] = in ? p.pb[cb + e] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < H_PER; ++i)
+                if (h_src[i] >= 0) hreg[i] = prologue_apply<T>(hreg[i], la, lb);
+        }
+        char* dst = halo + buf * HALO_BYTES;
+#pragma unroll
+        for (int i = 0; i < H_PER; ++i)
+            if (h_lds[i] >= 0) *reinterpret_cast<uint4*>(dst + h_lds[i]) = hreg[i];
+    };
+    auto w_load = [&](int s) {
+        int kc = s / 9, tap = s - kc * 9;
+        const char* wsrc = (const char*)p.w + ((long long)(tap * nkc + kc) * p.co_pad + co0) * 64;
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) wreg[i] = *reinterpret_cast<const uint4*>(wsrc + (tid + i * 256) * 16);
+    };
+    auto w_store = [&](int slot) {
+        char* dst = wring + slot * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            int chunk = tid + i * 256;
+            *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = wreg[i];
+        }
+    };
+
+    float4v acc[WCO][WPX];
+#pragma unroll
+    for (int i = 0; i < WCO; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int lane_off = lds_row_off(lane & 15, lane >> 4);
+    const int lq = lane >> 4, lr = lane & 15;
+
+    // ---- prologue: halo(0) and W(0) into LDS, W(1) into registers
+    halo_load(0);
+    w_load(0);
+    halo_store(0, 0);
+    w_store(0);
+    if (nsteps > 1) w_load(1);
+    __syncthreads();
+
+    int s = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        const char* hb = halo + (kc & 1) * HALO_BYTES;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            if (s + 1 < nsteps) w_store((s + 1) % 3);
+            if (s + 2 < nsteps) w_load(s + 2);
+            if (tap == 0 && kc + 1 < nkc) halo_load(kc + 1);
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const char* ws = wring + (s % 3) * W_BYTES;
+            frag_t fa[WCO];
+#pragma unroll
+            for (int i = 0; i < WCO; ++i)
+                fa[i] = *reinterpret_cast<const frag_t*>(ws + (w_co * WCO + i) * 1024 + lane_off);
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) {
+                int pp = (w_px * ROWS + (j >> 1) + dy) * HX + (j & 1) * 16 + dx + lr;
+                frag_t fb = *reinterpret_cast<const frag_t*>(hb + pp * 64 + ((lq ^ (((pp >> 2) & 1) << 1)) << 4));
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);
+            }
+            if (tap == 7 && kc + 1 < nkc) halo_store(kc + 1, (kc + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue
+    float st[WCO][4], sq[WCO][4];
+#pragma unroll
+    for (int i = 0; i < WCO; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[i][r] = sq[i][r] = 0.f;
+    const int cgrp = lq * 4;
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
+        const bool pix_ok = oy < p.ho && ox < p.wo;
+        const long long m = ((long long)nimg * p.ho + oy) * p.wo + ox;
+#pragma unroll
+        for (int i = 0; i < WCO; ++i) {
+            const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+            if (!pix_ok || co >= p.cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const int nv = p.cout - co < 4 ? p.cout - co : 4;
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nv) v[r] += p.bias[co + r];
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            }
+            if (p.res) {
+                const T* rp = (const T*)p.res + m * p.res_pitch + co;
+                if (nv == 4) {
+                    if constexpr (sizeof(T) == 2) {
+                        half4 rv = *reinterpret_cast<const half4*>(rp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                    } else {
+                        float4v rv = *reinterpret_cast<const float4v*>(rp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    }
+                } else {
+                    for (int r = 0; r < nv; ++r) v[r] += to_f(rp[r]);
+                }
+            }
+            T* op = (T*)p.out + m * p.cout_pitch + co;
+            T tv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
+            if (nv == 4) {
+                if constexpr (sizeof(T) == 2) {
+                    half4 hv = {tv[0], tv[1], tv[2], tv[3]};
+                    *reinterpret_cast<half4*>(op) = hv;
+                } else {
+                    *reinterpret_cast<float4v*>(op) = (float4v){tv[0], tv[1], tv[2], tv[3]};
+                }
+            } else {
+                for (int r = 0; r < nv; ++r) op[r] = tv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < nv) {
+                    float f = to_f(tv[r]);   // statistics of the STORED value
+                    st[i][r] += f;
+                    sq[i][r] = fmaf(f, f, sq[i][r]);
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // reduce over the 16 pixel lanes that share lq, then over the NW_PX pixel waves via LDS
+        float* red = reinterpret_cast<float*>(smem);  // [NW_PX][TCO][2]; all LDS reads are done
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = st[i][r], b = sq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (lr == 0) {
+                    int cl = (w_co * WCO + i) * 16 + cgrp + r;
+                    red[(w_px * TCO + cl) * 2 + 0] = a;
+                    red[(w_px * TCO + cl) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < TCO && co0 + tid < p.cout) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW_PX; ++w) {
+                a += red[(w * TCO + tid) * 2 + 0];
+                b += red[(w * TCO + tid) * 2 + 1];
+            }
+            long long tile = ((long long)nimg * p.tiles_y + ty) * p.tiles_x + tx;
+            float* dst = p.stats + (tile * p.cout + co0 + tid) * 2;
+            dst[0] = a;
+            dst[1] = b;
+        }
+    }
+}
+
 // tile configuration chosen from cout (shared by pack + launch)
 struct TileCfg {
     int tco, tpx, id;
 };
 inline TileCfg choose_tile(int cout) {
     if (cout % 128 == 0) return {128, 128, 0};
-    if (cout % 64 == 0) return {64, 128, 1};
+    if (cout >= 64) return {64, 128, 1};   // co padded up to a multiple of 64 (e.g. 160 -> 192)
     if (cout <= 16) return {16, 256, 3};
     return {32, 256, 2};
 }
+// the halo kernel handles 3x3 / stride 1 / pad 1 with a 128- or 64-channel output tile
+inline bool halo_eligible(const elvis_conv_desc* d) {
+    return d->ksize == 3 && d->stride == 1 && d->pad_before == 1 && d->cout >= 64 &&
+           d->ho == (d->upsample ? 2 * d->h : d->h) && d->wo == (d->upsample ? 2 * d->w : d->w);
+}
+constexpr int HALO_TY = 8, HALO_TX = 32;
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
 
 int validate(const elvis_conv_desc* d) {
@@ -321,6 +600,25 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((conv_igemm_kernel<T, WCO, WPX, NW_CO, NW_PX>), dim3((unsigned)nblk), dim3(64 * NW_CO * NW_PX),
                        lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_conv2d");
+    return ELVIS_OK;
+}
+
+template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
+    constexpr size_t lds = 2 * (size_t)((HALO_TY + 2) * (HALO_TX + 2) * 64) + 3 * (size_t)TCO * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return ELVIS_E_RUNTIME;
+        }
+        attr_set = true;
+    }
+    long long nblk = (long long)a.n_co_tiles * a.tiles_x * a.tiles_y * a.n;
+    ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    ELVIS_CHECK_LAUNCH("elvis_conv2d(halo)");
     return ELVIS_OK;
 }
 
@@ -391,9 +689,14 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
     return ELVIS_OK;
 }
 
+extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
+    if (!d || !halo_eligible(d)) return 0;
+    return d->n * ((d->ho + HALO_TY - 1) / HALO_TY) * ((d->wo + HALO_TX - 1) / HALO_TX);
+}
+
 extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const void* w_packed,
                             const float* bias, const void* residual, int residual_pitch, const float* pa,
-                            const float* pb, void* out, elvis_stream_t stream) {
+                            const float* pb, void* out, float* stats, elvis_stream_t stream) {
     int rc = validate(d);
     if (rc) return rc;
     ELVIS_REQUIRE(x && w_packed && out, "elvis_conv2d: null pointer");
@@ -414,6 +717,16 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.M = (long long)d->n * d->ho * d->wo;
     a.n_co_tiles = a.co_pad / t.tco;
     a.n_px_tiles = (a.M + t.tpx - 1) / t.tpx;
+    a.stats = stats;
+    a.tiles_x = (d->wo + HALO_TX - 1) / HALO_TX;
+    a.tiles_y = (d->ho + HALO_TY - 1) / HALO_TY;
+    if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
+        ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
+        if (d->dtype == ELVIS_F16)
+            return t.tco == 128 ? launch_halo<half_t, 128>(a, (hipStream_t)stream) : launch_halo<half_t, 64>(a, (hipStream_t)stream);
+        return t.tco == 128 ? launch_halo<float, 128>(a, (hipStream_t)stream) : launch_halo<float, 64>(a, (hipStream_t)stream);
+    }
+    ELVIS_REQUIRE(!stats, "elvis_conv2d: fused statistics need a 3x3/stride-1 conv with cout >= 64 (query elvis_conv_stats_tiles)");
     if (d->dtype == ELVIS_F16) return dispatch<half_t>(a, t.id, (hipStream_t)stream);
     return dispatch<float>(a, t.id, (hipStream_t)stream);
 }

@@ -62,6 +62,35 @@ __global__ __launch_bounds__(256) void gn_channel_sums_kernel(const T* __restric
     }
 }
 
+// sums[n, coff + c] = sum over the image's tiles of partials[tile][c][0..1] (fp64 accumulation,
+// fixed order -> bit-reproducible).  grid = (c, n), one workgroup per channel.
+__global__ __launch_bounds__(256) void gn_partials_reduce_kernel(const float* __restrict__ partials,
+                                                                 int tiles_per_image, int c,
+                                                                 double* __restrict__ sums, int ctot, int coff) {
+    __shared__ double ra[256], rb[256];
+    const int ch = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    double a = 0, b = 0;
+    const float* base = partials + ((long long)n * tiles_per_image * c + ch) * 2;
+    for (int t = tid; t < tiles_per_image; t += 256) {
+        a += (double)base[(long long)t * c * 2 + 0];
+        b += (double)base[(long long)t * c * 2 + 1];
+    }
+    ra[tid] = a;
+    rb[tid] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            ra[tid] += ra[tid + o];
+            rb[tid] += rb[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        sums[((long long)n * ctot + coff + ch) * 2 + 0] = ra[0];
+        sums[((long long)n * ctot + coff + ch) * 2 + 1] = rb[0];
+    }
+}
+
 __global__ void gn_affine_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ scale,
                                  const float* __restrict__ shift, float* __restrict__ pa, float* __restrict__ pb,
@@ -194,6 +223,16 @@ extern "C" int elvis_groupnorm_sums(const void* x, int dtype, int n, int hw, int
     else
         ELVIS_REQUIRE(false, "elvis_groupnorm_sums: bad dtype");
     ELVIS_CHECK_LAUNCH("elvis_groupnorm_sums");
+    return ELVIS_OK;
+}
+
+extern "C" int elvis_gn_partials_to_sums(const float* partials, int tiles_per_image, int n, int c, double* sums,
+                                         int sums_ctot, int sums_coff, elvis_stream_t stream) {
+    ELVIS_REQUIRE(partials && sums && tiles_per_image > 0 && n > 0 && c > 0, "elvis_gn_partials_to_sums: bad argument");
+    ELVIS_REQUIRE(sums_coff >= 0 && sums_coff + c <= sums_ctot, "elvis_gn_partials_to_sums: channel slice outside buffer");
+    hipLaunchKernelGGL(gn_partials_reduce_kernel, dim3(c, n), dim3(256), 0, (hipStream_t)stream, partials,
+                       tiles_per_image, c, sums, sums_ctot, sums_coff);
+    ELVIS_CHECK_LAUNCH("elvis_gn_partials_to_sums");
     return ELVIS_OK;
 }
 

@@ -26,9 +26,11 @@ def pitch_for(c: int) -> int:
 
 @dataclass
 class Act:
-    """NHWC activation: t[n,h,w,pitch], logical channels c."""
+    """NHWC activation: t[n,h,w,pitch], logical channels c.  `stats` (optional) holds the per-tile
+    GroupNorm partial sums f32[n*tiles, c, 2] the producing conv wrote for this tensor."""
     t: torch.Tensor
     c: int
+    stats: Optional[torch.Tensor] = None
 
     @property
     def n(self): return self.t.shape[0]
@@ -181,7 +183,8 @@ class PackedConv:
         self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
 
     def __call__(self, x: Act, x2: Optional[Act] = None, *, stride=1, pad=None, upsample=False, act=0,
-                 residual: Optional[Act] = None, prologue=None, out: Optional[Act] = None, ho=None, wo=None) -> Act:
+                 residual: Optional[Act] = None, prologue=None, out: Optional[Act] = None, ho=None, wo=None,
+                 want_stats: bool = False) -> Act:
         if x.c != self.cin or (x2.c if x2 is not None else 0) != self.cin2:
             raise ValueError(f"conv: expected inputs with {self.cin}+{self.cin2} channels, got {x.c}+{x2.c if x2 else 0}")
         d = ConvDesc()
@@ -203,11 +206,44 @@ class PackedConv:
         if prologue is not None:
             pa, pb = prologue
             d.prologue = 1
+        stats = None
+        tiles = lib().elvis_conv_stats_tiles(C.byref(d))
+        if want_stats and tiles > 0:
+            stats = torch.empty((tiles, self.cout, 2), dtype=torch.float32, device=x.t.device)
+        out.stats = stats
+        prof = CONV_PROFILER
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(lib().elvis_conv2d(C.byref(d), ptr(x.t), ptr(x2.t) if x2 is not None else 0, ptr(self.packed),
                                  ptr(self.bias), ptr(residual.t) if residual is not None else 0,
                                  residual.pitch if residual is not None else 0, ptr(pa), ptr(pb), ptr(out.t),
-                                 _s(x.t)), x.t.device)
+                                 ptr(stats), _s(x.t)), x.t.device)
+        if prof is not None:
+            e1.record()
+            flops = 2.0 * self.ksize * self.ksize * (self.cin + self.cin2) * self.cout * x.n * ho * wo
+            prof.append((conv_kernel_name(self.cout, x.dtype_code, tiles > 0), flops, e0, e1))
         return out
+
+
+# When set to a list, every conv launch appends (kernel_name, algorithmic_flops, start_evt, end_evt);
+# the events are recorded on the stream the kernel is launched on (torch's current stream).
+CONV_PROFILER = None
+
+
+def conv_kernel_name(cout: int, dtype_code: int, halo: bool) -> str:
+    """Name of the kernel instantiation `elvis_conv2d` dispatches to (conv.hip choose_tile /
+    halo_eligible): conv3x3_halo_kernel<T,TCO> or conv_igemm_kernel<T,WCO,WPX,NW_CO,NW_PX>."""
+    t = "half" if dtype_code == L.F16 else "float"
+    if halo:
+        return f"conv3x3_halo_kernel<{t},{128 if cout % 128 == 0 else 64}>"
+    if cout % 128 == 0:
+        return f"conv_igemm_kernel<{t},4,4,2,2>"
+    if cout >= 64:
+        return f"conv_igemm_kernel<{t},2,4,2,2>"
+    if cout <= 16:
+        return f"conv_igemm_kernel<{t},1,4,1,4>"
+    return f"conv_igemm_kernel<{t},2,4,1,4>"
 
 
 def groupnorm_affine(xs, gamma, beta, groups, eps, scale=None, shift=None):
@@ -220,7 +256,12 @@ def groupnorm_affine(xs, gamma, beta, groups, eps, scale=None, shift=None):
     sums = torch.zeros((n, ctot, 2), dtype=torch.float64, device=dev)
     off = 0
     for x in xs:
-        check(lib().elvis_groupnorm_sums(ptr(x.t), x.dtype_code, n, hw, x.c, x.pitch, ptr(sums), ctot, off, _s(x.t)), dev)
+        if x.stats is not None:   # fused: the producing conv already wrote per-tile partial sums
+            check(lib().elvis_gn_partials_to_sums(ptr(x.stats), x.stats.shape[0] // n, n, x.c, ptr(sums), ctot, off,
+                                                  _s(x.t)), dev)
+        else:
+            check(lib().elvis_groupnorm_sums(ptr(x.t), x.dtype_code, n, hw, x.c, x.pitch, ptr(sums), ctot, off,
+                                             _s(x.t)), dev)
         off += x.c
     pa = torch.empty((n, ctot), dtype=torch.float32, device=dev)
     pb = torch.empty((n, ctot), dtype=torch.float32, device=dev)

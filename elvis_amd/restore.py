@@ -86,15 +86,44 @@ def get_sinsr_upsample_fn(device, *, scale: int = 2, seed: int = DEFAULT_SEED, f
     return upsample_fn
 
 
+def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, levels_d: torch.Tensor, block_size: int,
+                                 frame_indices: Sequence[int], seed: int = DEFAULT_SEED, swap_rb: bool = True,
+                                 noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The north-star Downsample path, fully on device: whole frame /4 (INTER_AREA, elvis.py:2565)
+    -> ONE SinSR 4x call (README.md:50) -> final-stage paste of elvis.py:2584-2595 at f=1
+    (`level == 0 ? decoded frame : SR`).  Frames whose map is all zero skip the network.
+    `noise` ([n,3,Hp,Wp] f32, resident) may be passed to keep host RNG out of a timed region."""
+    n, H, W, _ = frames_d.shape
+    if H % 4 or W % 4 or H % block_size or W % block_size:
+        raise ValueError("Image dimensions must be divisible by block_size and by 4.")
+    if out is None:
+        out = torch.empty_like(frames_d)
+    active = (levels_d > 0).flatten(1).any(dim=1).tolist()
+    with torch.cuda.device(model.device):
+        for i in range(n):
+            f = frames_d[i:i + 1]
+            if not active[i]:
+                out[i:i + 1] = f
+                continue
+            lr = ops.area_downscale_u8(f, 4)
+            nz = noise[i:i + 1] if noise is not None else model.make_noise(seed, [frame_indices[i]], H // 4, W // 4)
+            sr = model.forward(lr, nz, swap_rb=swap_rb)
+            ops.recompose_u8(f, sr, levels_d[i:i + 1], block_size, 0, out=out[i:i + 1])
+    return out
+
+
 def restore_frames_sinsr(frames: List[np.ndarray], downscale_maps: np.ndarray, block_size: int, device,
                          *, seed: int = DEFAULT_SEED, first_frame_index: int = 0, fp32: bool = False,
-                         staged_2x: bool = False, cfg: Optional[SinSRConfig] = None, **_ignored) -> List[np.ndarray]:
+                         schedule: str = "single4x", staged_2x: bool = False, cfg: Optional[SinSRConfig] = None,
+                         **_ignored) -> List[np.ndarray]:
     """Pure restoration function (no file IO, no parallelisation), drop-in for
     `restore_frames_realesrgan` (elvis.py:2640-2682): BGR uint8 frames + per-block log2
     downscale maps -> restored frames.
 
-    Default: native 4x stages (one SinSR call from the /4 level, README.md:50).  `staged_2x=True`
-    reproduces the reference's 2x-per-stage loop with the 4x net area-halved per stage.
+    schedule="single4x" (default, the north-star path): one SinSR 4x call from the /4 level per
+    frame, whatever the map's maximum (README.md:50).  schedule="staged": the coarse-to-fine loop
+    of elvis.py:2570-2598 generalised to 4x stages (`staged_2x=True`: the reference's 2x-per-stage
+    loop with the 4x net area-halved per stage).
     Unknown model kwargs of the reference call (model_name, tile, ...) are accepted and ignored
     (the `**kwargs` convention of the P3 surface, utils.py:1428).
     """
@@ -106,6 +135,11 @@ def restore_frames_sinsr(frames: List[np.ndarray], downscale_maps: np.ndarray, b
         frames_d = frames_to_device(frames, model.device)
         n = frames_d.shape[0]
         maps_d = maps_to_device(downscale_maps, n, model.device)
+        if schedule == "single4x":
+            gidx = [first_frame_index + i for i in range(n)]
+            return frames_to_host(restore_clip_single4x_device(model, frames_d, maps_d, block_size, gidx, seed))
+        if schedule != "staged":
+            raise ValueError(f"unknown schedule '{schedule}'")
         out = torch.empty_like(frames_d)
         # the reference derives the stage schedule from each frame's own max level
         # (elvis.py:2561): group frames by it so a batch shares one schedule.

@@ -56,7 +56,7 @@ class _ResBlock:
         xs = [x] if x2 is None else [x, x2]
         pa, pb = ops.groupnorm_affine(xs, self.norm1.gamma, self.norm1.beta, self.groups, self.eps)
         if fuse_gn:
-            h = self.conv1(x, x2, prologue=(pa, pb))
+            h = self.conv1(x, x2, prologue=(pa, pb), want_stats=True)
         else:
             a1 = ops.affine_act(x, pa[:, :x.c].contiguous(), pb[:, :x.c].contiguous(), act=2)
             a2 = None
@@ -68,7 +68,7 @@ class _ResBlock:
                                       scale=self.scale, shift=self.shift)
         res = x if self.skip is None else self.skip(x, x2)
         if fuse_gn:
-            return self.conv2(h, prologue=(pa, pb), residual=res)
+            return self.conv2(h, prologue=(pa, pb), residual=res, want_stats=True)
         ops.affine_act(h, pa, pb, act=2, out=h)
         return self.conv2(h, residual=res)
 
@@ -229,7 +229,7 @@ class SinSRModel:
                 elif kind == "down":
                     h = m(h, stride=2)
                 elif kind == "up":
-                    h = m(h, upsample=True)
+                    h = m(h, upsample=True, want_stats=self.fuse_gn)
                 else:
                     h = m(h)
             return h
@@ -245,7 +245,7 @@ class SinSRModel:
         return self._gn_silu_conv(h, self.u_out_norm, self.u_out_conv, 1e-5)
 
     def encode(self, x: Act) -> Act:
-        h = self.e_conv_in(x)
+        h = self.e_conv_in(x, want_stats=self.fuse_gn)
         for blocks, ds in self.e_down:
             for b in blocks:
                 h = b(h, fuse_gn=self.fuse_gn)
@@ -260,14 +260,14 @@ class SinSRModel:
         idx = None
         if self.cfg.quantize if quantize is None else quantize:
             z, idx = ops.vq_nearest(z, self.codebook, want_idx=True)
-        h = self.d_conv_in(self.post_quant_conv(z))
+        h = self.d_conv_in(self.post_quant_conv(z), want_stats=self.fuse_gn)
         for b in self.d_mid:
             h = b(h, fuse_gn=self.fuse_gn)
         for blocks, us in self.d_up:
             for b in blocks:
                 h = b(h, fuse_gn=self.fuse_gn)
             if us is not None:
-                h = us(h, upsample=True)
+                h = us(h, upsample=True, want_stats=self.fuse_gn)
         out = self._gn_silu_conv(h, self.d_norm_out, self.d_conv_out, 1e-6)
         return (out, idx) if want_idx else out
 

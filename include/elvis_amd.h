@@ -138,13 +138,24 @@ size_t elvis_conv_packed_weight_bytes(const elvis_conv_desc* d);
 int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_oihw, void* packed,
                             elvis_stream_t stream);
 
-/* y = act(conv(x [,x2]) + bias) + residual.  Implicit-GEMM on MFMA.  `bias` f32[cout] or NULL,
- * `residual` same dtype/pitch as out or NULL, `pa`,`pb` f32[n, cin+cin2] for the prologue.
+/* y = act(conv(prologue(x [,x2])) + bias) + residual.  Implicit-GEMM on MFMA.  `bias` f32[cout] or
+ * NULL, `residual` same dtype as out or NULL, `pa`,`pb` f32[n, cin+cin2] for the prologue.
+ * `stats` (may be NULL): per-tile GroupNorm partial sums of the STORED output,
+ * f32[elvis_conv_stats_tiles(d)][cout][2]; only for convs where elvis_conv_stats_tiles(d) > 0
+ * (3x3 / stride 1 / pad 1 / cout >= 64, the LDS halo-tile kernel).
  * This is the slot where the reference calls RealESRGANer.enhance (elvis.py:2515) /
  * restore_images_batch (elvis.py:2963-2970): the conv/linear layers of the restorer. */
 int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const void* w_packed,
                  const float* bias, const void* residual, int residual_pitch, const float* pa,
-                 const float* pb, void* out, elvis_stream_t stream);
+                 const float* pb, void* out, float* stats, elvis_stream_t stream);
+
+/* Number of per-tile statistics rows `elvis_conv2d` writes for this conv (n * tiles per image),
+ * 0 when the conv cannot produce fused statistics. */
+int elvis_conv_stats_tiles(const elvis_conv_desc* d);
+
+/* sums[n, sums_coff + c, 0..1] = sum over the image's tiles of partials[tile][c][0..1] (f64). */
+int elvis_gn_partials_to_sums(const float* partials, int tiles_per_image, int n, int c, double* sums,
+                              int sums_ctot, int sums_coff, elvis_stream_t stream);
 
 /* GroupNorm statistics: per-(n,channel) sum and sum of squares, sums[n, sums_ctot, 2] f64
  * (f32 partials per workgroup, one f64 atomic per channel per workgroup).  The tensor's channels

@@ -46,4 +46,7 @@ def test_argument_validation_without_gpu():
     d.ksize = 5
     d.n = d.h = d.w = d.ho = d.wo = 1
     d.stride = 1
-    assert h.elvis_conv2d(C.byref(d), 16, None, 16, None, None, 0, None, None, 16, None) == -1
+    assert h.elvis_conv2d(C.byref(d), 16, None, 16, None, None, 0, None, None, 16, None, None) == -1
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 0
+    d.ksize, d.pad_before, d.h, d.w, d.ho, d.wo, d.n = 3, 1, 1080, 1920, 1080, 1920, 1
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 135 * 60

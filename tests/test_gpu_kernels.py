@@ -92,6 +92,66 @@ def test_conv_concat_residual_act_prologue(gpu_device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [
+    # c1, c2, cout, h, w, upsample   (3x3 / stride 1 / pad 1 -> LDS halo-tile kernel)
+    (128, 0, 128, 40, 70, False),     # several 8x32 tiles, ragged right/bottom edges
+    (64, 32, 192, 19, 45, False),     # virtual concat, TCO=64 tile with 3 co tiles
+    (160, 0, 160, 16, 64, False),     # cout padded 160 -> 192
+    (64, 0, 128, 13, 21, True),       # fused nearest-2x upsample
+    (3, 0, 64, 9, 33, False),         # cin < one K chunk
+])
+def test_conv_halo_fused(gpu_device, dtype, cfg):
+    """The halo kernel with everything fused: GN-affine+SiLU prologue, bias, residual, and the
+    per-tile GroupNorm partial sums of its output."""
+    from elvis_amd import ops
+    c1, c2, cout, h, w, ups = cfg
+    g = torch.Generator().manual_seed(12)
+    n = 2
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
+    ctot = c1 + c2
+    wt = torch.randn(cout, ctot, 3, 3, generator=g) / math.sqrt(ctot * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (2 * h, 2 * w) if ups else (h, w)
+    res = torch.randn(n, cout, ho, wo, generator=g)
+    pa = torch.rand(n, ctot, generator=g) + 0.5
+    pb = torch.randn(n, ctot, generator=g) * 0.2
+    conv = ops.PackedConv(wt, b, dtype, gpu_device, c1, c2)
+    a1 = _act(x1, dtype, gpu_device)
+    a2 = _act(x2, dtype, gpu_device) if c2 else None
+    ar = _act(res, dtype, gpu_device)
+    y = conv(a1, a2, upsample=ups, prologue=(pa.to(gpu_device), pb.to(gpu_device)), residual=ar, want_stats=True)
+    assert y.stats is not None
+    xcat = (torch.cat([x1, x2], 1) if c2 else x1).to(dtype).float()
+    xin = F.silu(xcat * pa[:, :, None, None] + pb[:, :, None, None])
+    if dtype == torch.float16:
+        xin = xin.half().float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wt.to(dtype).float(), b, padding=1) + res.to(dtype).float()
+    got = _nchw(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL[dtype]
+    # fused statistics == sums of the stored tensor
+    sums = torch.zeros((n, cout, 2), dtype=torch.float64, device=gpu_device)
+    from elvis_amd._lib import lib, check, ptr
+    check(lib().elvis_gn_partials_to_sums(ptr(y.stats), y.stats.shape[0] // n, n, cout, ptr(sums), cout, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+    s = sums.cpu()
+    gd = got.double()
+    assert torch.allclose(s[:, :, 0], gd.sum((2, 3)), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(s[:, :, 1], (gd * gd).sum((2, 3)), rtol=1e-5, atol=1e-2)
+    # and the same conv without the halo kernel (ELVIS_NO_HALO=1 is read per call)
+    import os
+    os.environ["ELVIS_NO_HALO"] = "1"
+    try:
+        y0 = conv(a1, a2, upsample=ups, prologue=(pa.to(gpu_device), pb.to(gpu_device)), residual=ar)
+    finally:
+        del os.environ["ELVIS_NO_HALO"]
+    assert (_nchw(y0) - got).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("c,groups", [(64, 32), (160, 32), (96, 8)])
 def test_groupnorm_silu(gpu_device, dtype, c, groups):
     from elvis_amd import ops

@@ -131,6 +131,11 @@ def test_restore_frames_sinsr_surface(gpu_device):
     frames = [rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8) for _ in range(3)]
     maps = rng.integers(0, 3, size=(3, 8, 12)).astype(np.int32)
     maps[2] = 0
+    for sched in ("staged", "single4x"):
+        o = restore.restore_frames_sinsr(frames, maps, 8, gpu_device, cfg=cfg, schedule=sched)
+        assert np.array_equal(o[2], frames[2])
+        k0 = np.repeat(np.repeat(maps[0] == 0, 8, 0), 8, 1)
+        assert np.array_equal(o[0][k0], frames[0][k0]) and not np.array_equal(o[0][~k0], frames[0][~k0])
     out = restore.restore_frames_sinsr(frames, maps, 8, gpu_device, cfg=cfg)
     assert len(out) == 3 and out[0].shape == (64, 96, 3) and out[0].dtype == np.uint8
     assert np.array_equal(out[2], frames[2])

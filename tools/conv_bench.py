@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of elvis_conv2d on the layer shapes that dominate the 1080p SinSR frame.
+    python tools/conv_bench.py [--dtype f16|f32] [--iters N] [--only NAME] [--prologue] [--stats]
+Random (gaussian) data, HIP-event timing on the launch stream, interleaved rounds."""
+import argparse, math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elvis_amd import ops
+
+SHAPES = {  # name: (cin, cin2, cout, h, w, k, upsample)
+    "dec128_1080p": (128, 0, 128, 1080, 1920, 3, False),
+    "dec256_540p": (256, 0, 256, 540, 960, 3, False),
+    "dec512_270p": (512, 0, 512, 270, 480, 3, False),
+    "dec_up512_540p": (512, 0, 512, 270, 480, 3, True),
+    "dec_up256_1080p": (256, 0, 256, 540, 960, 3, True),
+    "dec256to128_1080p": (256, 0, 128, 1080, 1920, 3, False),
+    "unet160_320x512": (160, 0, 160, 320, 512, 3, False),
+    "unet_cat640_80x128": (320, 320, 320, 80, 128, 3, False),
+    "lin192x768": (192, 0, 768, 320, 512, 1, False),
+}
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--prologue", action="store_true")
+    ap.add_argument("--stats", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dt = torch.float16 if a.dtype == "f16" else torch.float32
+    g = torch.Generator().manual_seed(0)
+    for name, (c1, c2, co, h, w, k, ups) in SHAPES.items():
+        if a.only and a.only not in name:
+            continue
+        wt = torch.randn(co, c1 + c2, k, k, generator=g) / math.sqrt((c1 + c2) * k * k)
+        conv = ops.PackedConv(wt, torch.randn(co, generator=g), dt, dev, c1, c2)
+        x = ops.Act(torch.randn((1, h, w, c1), device=dev, dtype=dt), c1)
+        x2 = ops.Act(torch.randn((1, h, w, c2), device=dev, dtype=dt), c2) if c2 else None
+        pro = None
+        if a.prologue:
+            pro = (torch.rand((1, c1 + c2), device=dev) + 0.5, torch.randn((1, c1 + c2), device=dev) * 0.1)
+        y = conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(a.iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ho, wo = (2 * h, 2 * w) if ups else (h, w)
+        fl = 2.0 * k * k * (c1 + c2) * co * ho * wo
+        t = sorted(ts)[len(ts) // 2]
+        print(f"{name:22s} {a.dtype} pro={int(a.prologue)} st={int(a.stats)}  {t:8.3f} ms  {fl / t / 1e9:8.1f} TFLOP/s  ({fl / 1e9:.0f} GFLOP)", flush=True)
+
+if __name__ == "__main__":
+    main()
