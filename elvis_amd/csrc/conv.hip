@@ -68,8 +68,9 @@ __device__ __forceinline__ int lds_row_off(int row, int q) {
     return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
-template <typename T> __device__ __forceinline__ uint4 prologue_apply(uint4 v, const float* pa, const float* pb);
-template <> __device__ __forceinline__ uint4 prologue_apply<float>(uint4 v, const float* pa, const float* pb) {
+template <typename T> struct PrologueVec { float a[DT<T>::VEC], b[DT<T>::VEC]; };
+template <typename T> __device__ __forceinline__ uint4 prologue_apply(uint4 v, const float (&pa)[DT<T>::VEC], const float (&pb)[DT<T>::VEC]);
+template <> __device__ __forceinline__ uint4 prologue_apply<float>(uint4 v, const float (&pa)[4], const float (&pb)[4]) {
     float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -78,12 +79,12 @@ template <> __device__ __forceinline__ uint4 prologue_apply<float>(uint4 v, cons
     }
     return v;
 }
-template <> __device__ __forceinline__ uint4 prologue_apply<half_t>(uint4 v, const float* pa, const float* pb) {
+template <> __device__ __forceinline__ uint4 prologue_apply<half_t>(uint4 v, const float (&pa)[8], const float (&pb)[8]) {
     half_t* hv = reinterpret_cast<half_t*>(&v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float t = fmaf((float)hv[i], pa[i], pb[i]);
-        hv[i] = (half_t)(t / (1.0f + __expf(-t)));
+        hv[i] = (half_t)(t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)));
     }
     return v;
 }
@@ -295,24 +296,28 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
 // Epilogue: bias / activation / residual, NHWC store, and per-tile GroupNorm partial sums
 // (sum, sum of squares per output channel) for the NEXT layer's normalisation - no atomics, the
 // partials are reduced by elvis_gn_partials_to_sums.
-template <typename T, int TCO>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
-    constexpr int TY = 8, TX = 32, HX = TX + 2, HY = TY + 2, HP = HX * HY;
+template <typename T, int TCO, int NT, int TY, bool PRO>
+__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
+    constexpr int TX = 32, HX = TX + 2, HY = TY + 2, HP = HX * HY;
     constexpr int HCH = HP * 4;
-    constexpr int H_PER = (HCH + 255) / 256;
+    constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
     constexpr int W_BYTES = TCO * 64;
-    constexpr int W_PER = W_BYTES / 16 / 256;
-    constexpr int NW_CO = TCO / 64, NW_PX = 4 / NW_CO;
+    constexpr int W_CHUNKS = W_BYTES / 16;
+    constexpr int W_PER = (W_CHUNKS + NT - 1) / NT;
+    constexpr int NW_CO = TCO / 64, NW_PX = (NT / 64) / NW_CO;
     constexpr int ROWS = TY / NW_PX;
     constexpr int WPX = ROWS * 2, WCO = 4;
     constexpr int VEC = DT<T>::VEC, KC = 4 * VEC;
     typedef typename Frag<T>::type frag_t;
-    static_assert(W_PER >= 1, "weight slot must cover the workgroup");
+    static_assert(ROWS * NW_PX == TY && ROWS >= 1, "tile rows must split evenly over the pixel waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;                     // 2 buffers of HALO_BYTES
     char* const wring = smem + 2 * HALO_BYTES;   // 3 slots of W_BYTES
+    // prologue table: per K chunk and 16-byte slice q, VEC x a then VEC x b (f32), so a thread's
+    // GroupNorm affine for the slice it stages is two LDS vector reads - no long-lived registers
+    float* const ptab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + 3 * W_BYTES);
 
     long long nblk = (long long)p.n_co_tiles * p.tiles_x * p.tiles_y * p.n;
     long long bid = blockIdx.x;
@@ -333,74 +338,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const int w_co = wave / NW_PX, w_px = wave % NW_PX;
     const int lh = p.upsample ? p.h * 2 : p.h, lw = p.upsample ? p.w_in * 2 : p.w_in;
 
-    // ---- halo staging plan: chunk = tid + 256*i -> (halo pixel, 16-byte channel slice q = tid&3)
-    int h_src[H_PER], h_lds[H_PER];
+    // ---- halo staging plan: chunk = tid + NT*i -> (halo pixel, 16-byte channel slice q = tid&3).
+    // Branch-free: out-of-image / out-of-range chunks load pixel 0 and are zeroed by a select, so
+    // the compiler can keep counted (not vmcnt(0)) waits on the prefetch pipeline.
+    int h_src[H_PER];
+    unsigned h_ok = 0;
 #pragma unroll
     for (int i = 0; i < H_PER; ++i) {
-        int chunk = tid + i * 256;
+        int chunk = tid + i * NT;
         int pix = chunk >> 2;
         int hy = pix / HX, hx = pix - hy * HX;
         int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
         bool ok = chunk < HCH && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
         int sy = p.upsample ? (gy >> 1) : gy, sx = p.upsample ? (gx >> 1) : gx;
-        h_src[i] = ok ? (nimg * p.h + sy) * p.w_in + sx : -1;
-        h_lds[i] = chunk < HCH ? lds_row_off(pix, chunk & 3) : -1;
+        h_src[i] = ok ? (nimg * p.h + sy) * p.w_in + sx : 0;
+        h_ok |= (ok ? 1u : 0u) << i;
     }
-    const int q4 = tid & 3;
+    const int q4 = tid & 3;   // NT is a multiple of 4: every chunk of this thread has the same q
     const int nkc = p.nkc;
     const int nsteps = nkc * 9;
 
+    // Two staging phases per K chunk keep only half of the halo registers live at a time:
+    // phase A = chunk slots [0, HA) loaded at tap 0, stored at tap 2; phase B = [HA, H_PER)
+    // loaded at tap 3, stored at tap 5.
+    constexpr int HA = (H_PER + 1) / 2;
     uint4 hreg[H_PER];
-    uint4 wreg[W_PER];
+    uint4 wreg0[W_PER], wreg1[W_PER], wreg2[W_PER];   // three named sets: never runtime-indexed
 
-    auto halo_load = [&](int kc) {
+    auto halo_load = [&](int kc, int i0, int i1) {
         const bool second = kc >= p.nkc1;
         const char* xsrc = (const char*)(second ? p.x2 : p.x);
         const int pitch = second ? p.cin2_pitch : p.cin_pitch;
         const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+        const int c0c = c0 < pitch ? c0 : 0;
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            hreg[i] = *reinterpret_cast<const uint4*>(xsrc + ((long long)h_src[i] * pitch + c0c) * (long long)sizeof(T));
+    };
+    auto halo_store = [&](int kc, int buf, int i0, int i1) {
+        const bool second = kc >= p.nkc1;
+        const int pitch = second ? p.cin2_pitch : p.cin_pitch;
+        const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
         const bool ch_ok = c0 < pitch;
-#pragma unroll
-        for (int i = 0; i < H_PER; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (h_src[i] >= 0 && ch_ok)
-                v = *reinterpret_cast<const uint4*>(xsrc + ((long long)h_src[i] * pitch + c0) * (long long)sizeof(T));
-            hreg[i] = v;
-        }
-    };
-    auto halo_store = [&](int kc, int buf) {
-        if (p.prologue) {
-            const bool second = kc >= p.nkc1;
-            const int cvalid = second ? p.cin2 : p.cin;
-            const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
-            const long long cb = (long long)nimg * (p.cin + p.cin2) + (second ? p.cin : 0) + c0;
-            float la[VEC], lb[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                bool in = (c0 + e) < cvalid;
-                la[e] = in ? p.pa[cb + e] : 0.0f;
-                lb[e] = in ? p.pb[cb + e] : 0.0f;
-            }
-#pragma unroll
-            for (int i = 0; i < H_PER; ++i)
-                if (h_src[i] >= 0) hreg[i] = prologue_apply<T>(hreg[i], la, lb);
-        }
         char* dst = halo + buf * HALO_BYTES;
+        float la[VEC], lb[VEC];
+        if (PRO) {
+            const float* tp = ptab + (kc * 4 + q4) * 2 * VEC;
 #pragma unroll
-        for (int i = 0; i < H_PER; ++i)
-            if (h_lds[i] >= 0) *reinterpret_cast<uint4*>(dst + h_lds[i]) = hreg[i];
+            for (int e = 0; e < VEC; e += 4) {
+                float4v a4 = *reinterpret_cast<const float4v*>(tp + e);
+                float4v b4 = *reinterpret_cast<const float4v*>(tp + VEC + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { la[e + k] = a4[k]; lb[e + k] = b4[k]; }
+            }
+        }
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            uint4 v = hreg[i];
+            if (PRO) v = prologue_apply<T>(v, la, lb);
+            const bool keep = ch_ok && ((h_ok >> i) & 1u);
+            v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+            int chunk = tid + i * NT;
+            if ((i + 1) * NT <= HCH || chunk < HCH)
+                *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = v;
+        }
     };
-    auto w_load = [&](int s) {
+    auto w_load = [&](int s, uint4 (&wr)[W_PER]) {
+        s = s < nsteps ? s : nsteps - 1;   // tail steps re-load the last slice (never consumed)
         int kc = s / 9, tap = s - kc * 9;
         const char* wsrc = (const char*)p.w + ((long long)(tap * nkc + kc) * p.co_pad + co0) * 64;
 #pragma unroll
-        for (int i = 0; i < W_PER; ++i) wreg[i] = *reinterpret_cast<const uint4*>(wsrc + (tid + i * 256) * 16);
+        for (int i = 0; i < W_PER; ++i) {
+            int chunk = tid + i * NT;
+            if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS) wr[i] = *reinterpret_cast<const uint4*>(wsrc + chunk * 16);
+        }
     };
-    auto w_store = [&](int slot) {
+    auto w_store = [&](const uint4 (&wr)[W_PER], int slot) {
         char* dst = wring + slot * W_BYTES;
 #pragma unroll
         for (int i = 0; i < W_PER; ++i) {
-            int chunk = tid + i * 256;
-            *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = wreg[i];
+            int chunk = tid + i * NT;
+            if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS)
+                *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = wr[i];
         }
     };
 
@@ -413,39 +432,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const int lane_off = lds_row_off(lane & 15, lane >> 4);
     const int lq = lane >> 4, lr = lane & 15;
 
-    // ---- prologue: halo(0) and W(0) into LDS, W(1) into registers
-    halo_load(0);
-    w_load(0);
-    halo_store(0, 0);
-    w_store(0);
-    if (nsteps > 1) w_load(1);
+    if (PRO) {
+        // table entry t = (kc*4 + q)*2*VEC + {0..VEC-1: a, VEC..2VEC-1: b}; channels past the
+        // logical count get a = b = 0 (silu(0) = 0 keeps zero padding exact)
+        const int ctot = p.cin + p.cin2;
+        for (int t2 = tid; t2 < nkc * 4 * VEC; t2 += NT) {
+            int kc = t2 / (4 * VEC), r = t2 - kc * 4 * VEC;       // r = q*VEC + e
+            bool second = kc >= p.nkc1;
+            int cl = (second ? kc - p.nkc1 : kc) * KC + r;         // channel within its input
+            bool in = cl < (second ? p.cin2 : p.cin);
+            long long g = (long long)nimg * ctot + (second ? p.cin : 0) + (in ? cl : 0);
+            int q = r / VEC, e = r - q * VEC;
+            ptab[(kc * 4 + q) * 2 * VEC + e] = in ? p.pa[g] : 0.0f;
+            ptab[(kc * 4 + q) * 2 * VEC + VEC + e] = in ? p.pb[g] : 0.0f;
+        }
+        __syncthreads();
+    }
+    // ---- prologue: halo(0) and W(0) into LDS; W(1..3) in flight in the three register sets
+    halo_load(0, 0, H_PER);
+    w_load(0, wreg0);
+    halo_store(0, 0, 0, H_PER);
+    w_store(wreg0, 0);
+    w_load(1, wreg1);
+    w_load(2, wreg2);
+    w_load(3, wreg0);
     __syncthreads();
 
-    int s = 0;
+    // Per-lane halo pixel index of the wave's first px sub-tile at tap (0,0); sub-tiles and taps
+    // add compile-time constants.
+    const int pp0 = (w_px * ROWS) * HX + lr;
+
+    // Step s = kc*9 + tap reads LDS slot s%3 = tap%3.  At its top, register set (tap+1)%3 (holding
+    // W(s+1), loaded three steps ago) is written to slot (tap+1)%3 and immediately re-armed with
+    // the load of W(s+4): every weight load has three full steps (>= 3 x 32 MFMAs per wave) to land.
+#define ELVIS_TAP_STEP(TAP, WR)                                                                        \
+    {                                                                                                  \
+        const int s = s0 + TAP;                                                                        \
+        w_store(WR, (TAP + 1) % 3);                                                                    \
+        w_load(s + 4, WR);                                                                             \
+        if (TAP == 0) halo_load(kcn, 0, HA);                                                           \
+        if (TAP == 3) halo_load(kcn, HA, H_PER);                                                       \
+        constexpr int dy = TAP / 3, dx = TAP % 3;                                                      \
+        const char* ws = wring + (TAP % 3) * W_BYTES;                                                  \
+        int ppt = pp0;                                                                                 \
+        asm volatile("" : "+v"(ppt)); /* keep 72 fragment addresses from being hoisted and kept live */ \
+        frag_t fa[WCO];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < WCO; ++i)                                                \
+            fa[i] = *reinterpret_cast<const frag_t*>(ws + (w_co * WCO + i) * 1024 + lane_off);         \
+        _Pragma("unroll") for (int j = 0; j < WPX; ++j) {                                              \
+            int pp = ppt + ((j >> 1) + dy) * HX + (j & 1) * 16 + dx;                                   \
+            frag_t fb = *reinterpret_cast<const frag_t*>(hb + pp * 64 + ((lq ^ (((pp >> 2) & 1) << 1)) << 4)); \
+            _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);            \
+        }                                                                                              \
+        if (TAP == 2) halo_store(kcn, (kc + 1) & 1, 0, HA);                                            \
+        if (TAP == 5) halo_store(kcn, (kc + 1) & 1, HA, H_PER);                                        \
+        __syncthreads();                                                                               \
+    }
     for (int kc = 0; kc < nkc; ++kc) {
         const char* hb = halo + (kc & 1) * HALO_BYTES;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++s) {
-            if (s + 1 < nsteps) w_store((s + 1) % 3);
-            if (s + 2 < nsteps) w_load(s + 2);
-            if (tap == 0 && kc + 1 < nkc) halo_load(kc + 1);
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const char* ws = wring + (s % 3) * W_BYTES;
-            frag_t fa[WCO];
-#pragma unroll
-            for (int i = 0; i < WCO; ++i)
-                fa[i] = *reinterpret_cast<const frag_t*>(ws + (w_co * WCO + i) * 1024 + lane_off);
-#pragma unroll
-            for (int j = 0; j < WPX; ++j) {
-                int pp = (w_px * ROWS + (j >> 1) + dy) * HX + (j & 1) * 16 + dx + lr;
-                frag_t fb = *reinterpret_cast<const frag_t*>(hb + pp * 64 + ((lq ^ (((pp >> 2) & 1) << 1)) << 4));
-#pragma unroll
-                for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);
-            }
-            if (tap == 7 && kc + 1 < nkc) halo_store(kc + 1, (kc + 1) & 1);
-            __syncthreads();
-        }
+        const int s0 = kc * 9;
+        const int kcn = kc + 1 < nkc ? kc + 1 : kc;   // last chunk re-stages itself into the idle buffer
+        ELVIS_TAP_STEP(0, wreg1)
+        ELVIS_TAP_STEP(1, wreg2)
+        ELVIS_TAP_STEP(2, wreg0)
+        ELVIS_TAP_STEP(3, wreg1)
+        ELVIS_TAP_STEP(4, wreg2)
+        ELVIS_TAP_STEP(5, wreg0)
+        ELVIS_TAP_STEP(6, wreg1)
+        ELVIS_TAP_STEP(7, wreg2)
+        ELVIS_TAP_STEP(8, wreg0)
     }
+#undef ELVIS_TAP_STEP
 
     // ---- epilogue
     float st[WCO][4], sq[WCO][4];
@@ -567,7 +624,10 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
     return d->ksize == 3 && d->stride == 1 && d->pad_before == 1 && d->cout >= 64 &&
            d->ho == (d->upsample ? 2 * d->h : d->h) && d->wo == (d->upsample ? 2 * d->w : d->w);
 }
-constexpr int HALO_TY = 8, HALO_TX = 32;
+// 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
+// (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
+constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TX = 32;
+inline int halo_ty(int prologue) { return prologue ? HALO_TY_PRO : HALO_TY; }
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
 
 int validate(const elvis_conv_desc* d) {
@@ -603,12 +663,16 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return ELVIS_OK;
 }
 
-template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
-    constexpr size_t lds = 2 * (size_t)((HALO_TY + 2) * (HALO_TX + 2) * 64) + 3 * (size_t)TCO * 64;
+template <typename T, int TCO, bool PRO> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NT = 512;
+    constexpr int TY = PRO ? HALO_TY_PRO : HALO_TY;
+    const size_t lds_fixed = 2 * (size_t)((TY + 2) * (HALO_TX + 2) * 64) + 3 * (size_t)TCO * 64;
+    const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
+    ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
             return ELVIS_E_RUNTIME;
@@ -617,9 +681,13 @@ template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t st
     }
     long long nblk = (long long)a.n_co_tiles * a.tiles_x * a.tiles_y * a.n;
     ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_conv2d(halo)");
     return ELVIS_OK;
+}
+
+template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
+    return a.prologue ? launch_halo_p<T, TCO, true>(a, stream) : launch_halo_p<T, TCO, false>(a, stream);
 }
 
 template <typename T> int dispatch(const ConvArgs& a, int id, hipStream_t stream) {
@@ -691,7 +759,8 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
 
 extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     if (!d || !halo_eligible(d)) return 0;
-    return d->n * ((d->ho + HALO_TY - 1) / HALO_TY) * ((d->wo + HALO_TX - 1) / HALO_TX);
+    int ty = halo_ty(d->prologue);
+    return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
 }
 
 extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const void* w_packed,
@@ -719,7 +788,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.n_px_tiles = (a.M + t.tpx - 1) / t.tpx;
     a.stats = stats;
     a.tiles_x = (d->wo + HALO_TX - 1) / HALO_TX;
-    a.tiles_y = (d->ho + HALO_TY - 1) / HALO_TY;
+    a.tiles_y = (d->ho + halo_ty(d->prologue) - 1) / halo_ty(d->prologue);
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
         if (d->dtype == ELVIS_F16)
