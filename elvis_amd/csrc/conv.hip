@@ -302,9 +302,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
-    constexpr int W_BYTES = TCO * 64;
-    constexpr int W_CHUNKS = W_BYTES / 16;
-    constexpr int W_PER = (W_CHUNKS + NT - 1) / NT;
+    constexpr int W_TAP_BYTES = TCO * 64;                 // one (tap, chunk) weight slice
+    constexpr int W_BYTES = 3 * W_TAP_BYTES;              // one LDS slot = the 3 taps of a kernel row
+    constexpr int W_CHUNKS = W_TAP_BYTES / 16;
+    constexpr int W_PER = (W_CHUNKS + NT - 1) / NT;       // 16-byte chunks per thread per tap
     constexpr int NW_CO = TCO / 64, NW_PX = (NT / 64) / NW_CO;
     constexpr int ROWS = TY / NW_PX;
     constexpr int WPX = ROWS * 2, WCO = 4;
@@ -356,14 +357,21 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     }
     const int q4 = tid & 3;   // NT is a multiple of 4: every chunk of this thread has the same q
     const int nkc = p.nkc;
-    const int nsteps = nkc * 9;
+    const int nrows = nkc * 3;   // row steps: one kernel row (3 taps) of one K chunk per barrier
 
     // Two staging phases per K chunk keep only half of the halo registers live at a time:
     // phase A = chunk slots [0, HA) loaded at tap 0, stored at tap 2; phase B = [HA, H_PER)
     // loaded at tap 3, stored at tap 5.
     constexpr int HA = (H_PER + 1) / 2;
     uint4 hreg[H_PER];
-    uint4 wreg0[W_PER], wreg1[W_PER], wreg2[W_PER];   // three named sets: never runtime-indexed
+    uint4 wr0[W_PER], wr1[W_PER], wr2[W_PER];   // the three taps of the NEXT kernel row
+
+    int wl_off[W_PER];
+#pragma unroll
+    for (int i = 0; i < W_PER; ++i) {
+        int chunk = tid + i * NT;
+        wl_off[i] = lds_row_off(chunk >> 2, chunk & 3);
+    }
 
     auto halo_load = [&](int kc, int i0, int i1) {
         const bool second = kc >= p.nkc1;
@@ -403,24 +411,35 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = v;
         }
     };
-    auto w_load = [&](int s, uint4 (&wr)[W_PER]) {
-        s = s < nsteps ? s : nsteps - 1;   // tail steps re-load the last slice (never consumed)
-        int kc = s / 9, tap = s - kc * 9;
-        const char* wsrc = (const char*)p.w + ((long long)(tap * nkc + kc) * p.co_pad + co0) * 64;
+    // row step r = kc*3 + dy: the three taps (dy, 0..2) of K chunk kc
+    auto w_load1 = [&](const char* wsrc, uint4 (&wr)[W_PER]) {
 #pragma unroll
         for (int i = 0; i < W_PER; ++i) {
             int chunk = tid + i * NT;
             if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS) wr[i] = *reinterpret_cast<const uint4*>(wsrc + chunk * 16);
         }
     };
-    auto w_store = [&](const uint4 (&wr)[W_PER], int slot) {
-        char* dst = wring + slot * W_BYTES;
+    auto w_load = [&](int r) {
+        r = r < nrows ? r : nrows - 1;   // tail rows re-load the last slice (never consumed)
+        int kc = r / 3, dy = r - kc * 3;
+        const long long tap_stride = (long long)nkc * p.co_pad * 64;
+        const char* wsrc = (const char*)p.w + ((long long)(dy * 3 * nkc + kc) * p.co_pad + co0) * 64;
+        w_load1(wsrc, wr0);
+        w_load1(wsrc + tap_stride, wr1);
+        w_load1(wsrc + 2 * tap_stride, wr2);
+    };
+    auto w_store1 = [&](char* dst, const uint4 (&wr)[W_PER]) {
 #pragma unroll
         for (int i = 0; i < W_PER; ++i) {
             int chunk = tid + i * NT;
-            if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS)
-                *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = wr[i];
+            if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS) *reinterpret_cast<uint4*>(dst + wl_off[i]) = wr[i];
         }
+    };
+    auto w_store = [&](int slot) {
+        char* dst = wring + slot * W_BYTES;
+        w_store1(dst, wr0);
+        w_store1(dst + W_TAP_BYTES, wr1);
+        w_store1(dst + 2 * W_TAP_BYTES, wr2);
     };
 
     float4v acc[WCO][WPX];
@@ -448,61 +467,82 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         }
         __syncthreads();
     }
-    // ---- prologue: halo(0) and W(0) into LDS; W(1..3) in flight in the three register sets
+    // ---- prologue: halo(0) and weight row 0 into LDS; weight row 1 in flight in registers
     halo_load(0, 0, H_PER);
-    w_load(0, wreg0);
+    w_load(0);
     halo_store(0, 0, 0, H_PER);
-    w_store(wreg0, 0);
-    w_load(1, wreg1);
-    w_load(2, wreg2);
-    w_load(3, wreg0);
+    w_store(0);
+    w_load(1);
     __syncthreads();
 
-    // Per-lane halo pixel index of the wave's first px sub-tile at tap (0,0); sub-tiles and taps
-    // add compile-time constants.
+    // B-fragment addressing with ZERO per-read VALU.  A lane reads halo pixel x + C (x = its pixel at
+    // tap (0,0) of the wave's first sub-tile, C a compile-time pixel offset) at byte
+    //   (x+C)*64 + ((lq ^ (swz(x+C) << 1)) << 4),   swz(v) = (v >> 2) & 1.
+    // With C = 4*Cq + Cr:  swz(x+C) = swz(x) ^ (Cq & 1) ^ carry(x & 3, Cr), so eight per-lane bases
+    // bbase[Cr][Cq & 1] = x*64 + ((lq ^ ((swz(x) ^ carry(x&3,Cr) ^ (Cq&1)) << 1)) << 4) turn every read
+    // into `ds_read_b128 v, bbase[..] offset:C*64`.
     const int pp0 = (w_px * ROWS) * HX + lr;
+    int bb[4][2];   // bases into halo buffer 0; toggled by +-HALO_BYTES as the K chunks alternate
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int carry = ((pp0 & 3) + r) >> 2;
+            int bit = ((pp0 >> 2) & 1) ^ carry ^ e;
+            bb[r][e] = pp0 * 64 + ((lq ^ (bit << 1)) << 4);
+        }
+    const int a_off = w_co * WCO * 1024 + lane_off;
 
-    // Step s = kc*9 + tap reads LDS slot s%3 = tap%3.  At its top, register set (tap+1)%3 (holding
-    // W(s+1), loaded three steps ago) is written to slot (tap+1)%3 and immediately re-armed with
-    // the load of W(s+4): every weight load has three full steps (>= 3 x 32 MFMAs per wave) to land.
-#define ELVIS_TAP_STEP(TAP, WR)                                                                        \
+    // Row step r = kc*3 + dy reads LDS weight slot r%3 = dy and halo buffer kc&1.  At its top the
+    // register set (holding row r+1, loaded one full row step = 3 x WCO*WPX MFMAs per wave ago) is
+    // written to slot (dy+1)%3 and re-armed with the load of row r+2.  One barrier per row step.
+    // The next K chunk's halo is staged in two register phases: A loaded at dy=0 / stored after the
+    // dy=0 MFMAs, B loaded at dy=1 / stored after the dy=1 MFMAs.
+#ifdef ELVIS_EXP_NOSTAGE   /* timing experiment only: no staging traffic in the loop (wrong results) */
+#define ELVIS_STAGE(x)
+#else
+#define ELVIS_STAGE(x) x
+#endif
+#ifdef ELVIS_EXP_NOBARRIER /* timing experiment only */
+#define ELVIS_BARRIER()
+#else
+#define ELVIS_BARRIER() __syncthreads()
+#endif
+#define ELVIS_ROW_STEP(DY)                                                                             \
     {                                                                                                  \
-        const int s = s0 + TAP;                                                                        \
-        w_store(WR, (TAP + 1) % 3);                                                                    \
-        w_load(s + 4, WR);                                                                             \
-        if (TAP == 0) halo_load(kcn, 0, HA);                                                           \
-        if (TAP == 3) halo_load(kcn, HA, H_PER);                                                       \
-        constexpr int dy = TAP / 3, dx = TAP % 3;                                                      \
-        const char* ws = wring + (TAP % 3) * W_BYTES;                                                  \
-        int ppt = pp0;                                                                                 \
-        asm volatile("" : "+v"(ppt)); /* keep 72 fragment addresses from being hoisted and kept live */ \
-        frag_t fa[WCO];                                                                                \
-        _Pragma("unroll") for (int i = 0; i < WCO; ++i)                                                \
-            fa[i] = *reinterpret_cast<const frag_t*>(ws + (w_co * WCO + i) * 1024 + lane_off);         \
-        _Pragma("unroll") for (int j = 0; j < WPX; ++j) {                                              \
-            int pp = ppt + ((j >> 1) + dy) * HX + (j & 1) * 16 + dx;                                   \
-            frag_t fb = *reinterpret_cast<const frag_t*>(hb + pp * 64 + ((lq ^ (((pp >> 2) & 1) << 1)) << 4)); \
-            _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);            \
+        ELVIS_STAGE(w_store((DY + 1) % 3);)                                                            \
+        ELVIS_STAGE(w_load(r0 + DY + 2);)                                                              \
+        ELVIS_STAGE(if (DY == 0) halo_load(kcn, 0, HA);)                                               \
+        ELVIS_STAGE(if (DY == 1) halo_load(kcn, HA, H_PER);)                                           \
+        _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                             \
+            const char* ws = wring + DY * W_BYTES + dx * W_TAP_BYTES + a_off;                          \
+            frag_t fa[WCO];                                                                            \
+            _Pragma("unroll") for (int i = 0; i < WCO; ++i)                                            \
+                fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 1024);                               \
+            _Pragma("unroll") for (int j = 0; j < WPX; ++j) {                                          \
+                const int C = ((j >> 1) + DY) * HX + (j & 1) * 16 + dx;                                \
+                frag_t fb = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64); \
+                _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);        \
+            }                                                                                          \
         }                                                                                              \
-        if (TAP == 2) halo_store(kcn, (kc + 1) & 1, 0, HA);                                            \
-        if (TAP == 5) halo_store(kcn, (kc + 1) & 1, HA, H_PER);                                        \
-        __syncthreads();                                                                               \
+        ELVIS_STAGE(if (DY == 0) halo_store(kcn, (kc + 1) & 1, 0, HA);)                                \
+        ELVIS_STAGE(if (DY == 1) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)                            \
+        ELVIS_BARRIER();                                                                               \
     }
     for (int kc = 0; kc < nkc; ++kc) {
-        const char* hb = halo + (kc & 1) * HALO_BYTES;
-        const int s0 = kc * 9;
+        const int r0 = kc * 3;
         const int kcn = kc + 1 < nkc ? kc + 1 : kc;   // last chunk re-stages itself into the idle buffer
-        ELVIS_TAP_STEP(0, wreg1)
-        ELVIS_TAP_STEP(1, wreg2)
-        ELVIS_TAP_STEP(2, wreg0)
-        ELVIS_TAP_STEP(3, wreg1)
-        ELVIS_TAP_STEP(4, wreg2)
-        ELVIS_TAP_STEP(5, wreg0)
-        ELVIS_TAP_STEP(6, wreg1)
-        ELVIS_TAP_STEP(7, wreg2)
-        ELVIS_TAP_STEP(8, wreg0)
+        ELVIS_ROW_STEP(0)
+        ELVIS_ROW_STEP(1)
+        ELVIS_ROW_STEP(2)
+        const int delta = (kc & 1) ? -HALO_BYTES : HALO_BYTES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bb[r][0] += delta;
+            bb[r][1] += delta;
+        }
     }
-#undef ELVIS_TAP_STEP
+#undef ELVIS_ROW_STEP
 
     // ---- epilogue
     float st[WCO][4], sq[WCO][4];
@@ -666,7 +706,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int TCO, bool PRO> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 512;
     constexpr int TY = PRO ? HALO_TY_PRO : HALO_TY;
-    const size_t lds_fixed = 2 * (size_t)((TY + 2) * (HALO_TX + 2) * 64) + 3 * (size_t)TCO * 64;
+    const size_t lds_fixed = 2 * (size_t)((TY + 2) * (HALO_TX + 2) * 64) + 9 * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
     static bool attr_set = false;

@@ -31,7 +31,7 @@ DEFAULT_SEED = 42  # the reference's default sampler seed (elvis.py:89, utils.py
 
 
 def get_sinsr_model(device, *, cfg: Optional[SinSRConfig] = None, fp32: bool = False, weight_seed: int = 0,
-                    state_dict=None, fuse_gn: bool = False) -> SinSRModel:
+                    state_dict=None, fuse_gn: bool = True) -> SinSRModel:
     """Get or create the cached SinSR runtime for `device` (thread-safe, never freed - the
     reference's cache policy, elvis.py:2611-2637)."""
     dev = torch.device(device)

@@ -115,7 +115,7 @@ class SinSRModel:
     """Weights resident in HBM, packed once; `forward` runs one batch of LR frames."""
 
     def __init__(self, cfg: SinSRConfig = SinSRConfig(), state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = False):
+                 device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = True):
         self.cfg, self.device, self.dtype, self.fuse_gn = cfg, torch.device(device), dtype, fuse_gn
         sd = state_dict if state_dict is not None else make_sinsr_weights(cfg, weight_seed)
         dev = self.device

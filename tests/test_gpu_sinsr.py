@@ -20,7 +20,7 @@ def _setup(cfg, h, w, dtype, dev, seed=0):
     from elvis_amd.weights import frame_noise, make_sinsr_weights
     from oracle import sinsr_ref as R
     sd = make_sinsr_weights(cfg, seed)
-    model = SinSRModel(cfg, sd, dev, dtype)
+    model = SinSRModel(cfg, sd, dev, dtype, fuse_gn=False)
     rng = np.random.default_rng(20260501)
     # smooth-ish synthetic LR content
     base = rng.random((h // 4 + 2, w // 4 + 2, 3)).astype(np.float32)
@@ -93,6 +93,22 @@ def test_tiny_f16_fast_mode(gpu_device):
     print("f16 max-abs", err)
     assert err < 3e-2                      # documented f16 bar (fp32 bar is 1e-3)
     assert _psnr(u8[0].cpu().numpy(), R.to_u8(ref).numpy()) > 40.0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.float16, 3e-2)])
+def test_fused_default_path_vs_oracle(gpu_device, dtype, tol):
+    """The DEFAULT product configuration (GroupNorm statistics from the producing conv's epilogue,
+    normalise+SiLU in the consuming conv's LDS prologue) against the CPU oracle."""
+    from elvis_amd.sinsr import SinSRModel
+    from elvis_amd.weights import tiny_config
+    from oracle import sinsr_ref as R
+    cfg = dataclasses.replace(tiny_config(), quantize=False)
+    sd, _, lr, noise = _setup(cfg, 40, 72, dtype, gpu_device)
+    model = SinSRModel(cfg, sd, gpu_device, dtype)
+    assert model.fuse_gn
+    f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)[1]
+    ref = R.sinsr_forward(sd, cfg, lr, noise)
+    assert (f32[0].cpu() - ref).abs().max().item() < tol
 
 
 def test_fused_gn_prologue_matches_unfused(gpu_device):
