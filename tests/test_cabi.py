@@ -49,4 +49,6 @@ def test_argument_validation_without_gpu():
     assert h.elvis_conv2d(C.byref(d), 16, None, 16, None, None, 0, None, None, 16, None, None) == -1
     assert h.elvis_conv_stats_tiles(C.byref(d)) == 0
     d.ksize, d.pad_before, d.h, d.w, d.ho, d.wo, d.n = 3, 1, 1080, 1920, 1080, 1920, 1
-    assert h.elvis_conv_stats_tiles(C.byref(d)) == 135 * 60
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 68 * 60      # 16 x 32 pixel tiles
+    d.prologue = 1
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 135 * 60     # 8 x 32 tiles with the fused prologue
