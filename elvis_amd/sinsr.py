@@ -52,25 +52,32 @@ class _ResBlock:
         if self.skip is None and cin2:
             raise ValueError("a concatenated input needs a skip projection")
 
+    # The fused prologue recomputes normalise+SiLU once per 128-channel output tile (and 1.33x for
+    # the halo); with >= 4 output tiles it is cheaper to materialise the activated tensor once
+    # (one extra read+write) and run the faster prologue-free 16x32-tile kernel.
+    FUSE_MAX_COUT = 256
+
     def __call__(self, x: Act, x2: Optional[Act] = None, fuse_gn=False) -> Act:
         xs = [x] if x2 is None else [x, x2]
         pa, pb = ops.groupnorm_affine(xs, self.norm1.gamma, self.norm1.beta, self.groups, self.eps)
-        if fuse_gn:
+        fuse1 = fuse_gn and self.conv1.cout <= self.FUSE_MAX_COUT
+        fuse2 = fuse_gn and self.conv2.cout <= self.FUSE_MAX_COUT
+        if fuse1:
             h = self.conv1(x, x2, prologue=(pa, pb), want_stats=True)
         else:
             a1 = ops.affine_act(x, pa[:, :x.c].contiguous(), pb[:, :x.c].contiguous(), act=2)
             a2 = None
             if x2 is not None:
                 a2 = ops.affine_act(x2, pa[:, x.c:].contiguous(), pb[:, x.c:].contiguous(), act=2)
-            h = self.conv1(a1, a2)
+            h = self.conv1(a1, a2, want_stats=fuse_gn)
             del a1, a2
         pa, pb = ops.groupnorm_affine([h], self.norm2.gamma, self.norm2.beta, self.groups, self.eps,
                                       scale=self.scale, shift=self.shift)
         res = x if self.skip is None else self.skip(x, x2)
-        if fuse_gn:
+        if fuse2:
             return self.conv2(h, prologue=(pa, pb), residual=res, want_stats=True)
         ops.affine_act(h, pa, pb, act=2, out=h)
-        return self.conv2(h, residual=res)
+        return self.conv2(h, residual=res, want_stats=fuse_gn)
 
 
 class _SwinLayer:
