@@ -296,19 +296,23 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
 // Epilogue: bias / activation / residual, NHWC store, and per-tile GroupNorm partial sums
 // (sum, sum of squares per output channel) for the NEXT layer's normalisation - no atomics, the
 // partials are reduced by elvis_gn_partials_to_sums.
-template <typename T, int TCO, int NT, int TY, bool PRO>
+template <typename T, int TCO, int NT, int TY, bool PRO, int KS = 3>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
-    constexpr int TX = 32, HX = TX + 2, HY = TY + 2, HP = HX * HY;
+    // KS = 3: 3x3 / pad 1 (halo of one pixel).  KS = 1: 1x1 conv / linear layer - the same staging
+    // pipeline with no halo and one tap per K chunk (HBM-bound: what matters is bytes in flight).
+    constexpr int PADH = KS / 2;
+    constexpr int TX = 32, HX = TX + 2 * PADH, HY = TY + 2 * PADH, HP = HX * HY;
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
     constexpr int W_TAP_BYTES = TCO * 64;                 // one (tap, chunk) weight slice
-    constexpr int W_BYTES = 3 * W_TAP_BYTES;              // one LDS slot = the 3 taps of a kernel row
+    constexpr int W_BYTES = KS * W_TAP_BYTES;             // one LDS slot = the KS taps of a kernel row
     constexpr int W_CHUNKS = W_TAP_BYTES / 16;
     constexpr int W_PER = (W_CHUNKS + NT - 1) / NT;       // 16-byte chunks per thread per tap
-    constexpr int NW_CO = TCO / 64, NW_PX = (NT / 64) / NW_CO;
+    // TCO in {16, 32, 64, 128}: up to 64 output channels per wave (WCO 16-row MFMA tiles)
+    constexpr int NW_CO = TCO >= 64 ? TCO / 64 : 1, NW_PX = (NT / 64) / NW_CO;
     constexpr int ROWS = TY / NW_PX;
-    constexpr int WPX = ROWS * 2, WCO = 4;
+    constexpr int WPX = ROWS * 2, WCO = TCO >= 64 ? 4 : TCO / 16;
     constexpr int VEC = DT<T>::VEC, KC = 4 * VEC;
     typedef typename Frag<T>::type frag_t;
     static_assert(ROWS * NW_PX == TY && ROWS >= 1, "tile rows must split evenly over the pixel waves");
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         int chunk = tid + i * NT;
         int pix = chunk >> 2;
         int hy = pix / HX, hx = pix - hy * HX;
-        int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+        int gy = oy0 + hy - PADH, gx = ox0 + hx - PADH;
         bool ok = chunk < HCH && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
         int sy = p.upsample ? (gy >> 1) : gy, sx = p.upsample ? (gx >> 1) : gx;
         h_src[i] = ok ? (nimg * p.h + sy) * p.w_in + sx : 0;
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     }
     const int q4 = tid & 3;   // NT is a multiple of 4: every chunk of this thread has the same q
     const int nkc = p.nkc;
-    const int nrows = nkc * 3;   // row steps: one kernel row (3 taps) of one K chunk per barrier
+    const int nrows = nkc * KS;   // row steps: one kernel row (KS taps) of one K chunk per barrier
 
     // Two staging phases per K chunk keep only half of the halo registers live at a time:
     // phase A = chunk slots [0, HA) loaded at tap 0, stored at tap 2; phase B = [HA, H_PER)
@@ -421,12 +425,14 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     };
     auto w_load = [&](int r) {
         r = r < nrows ? r : nrows - 1;   // tail rows re-load the last slice (never consumed)
-        int kc = r / 3, dy = r - kc * 3;
+        int kc = r / KS, dy = r - kc * KS;
         const long long tap_stride = (long long)nkc * p.co_pad * 64;
-        const char* wsrc = (const char*)p.w + ((long long)(dy * 3 * nkc + kc) * p.co_pad + co0) * 64;
+        const char* wsrc = (const char*)p.w + ((long long)(dy * KS * nkc + kc) * p.co_pad + co0) * 64;
         w_load1(wsrc, wr0);
-        w_load1(wsrc + tap_stride, wr1);
-        w_load1(wsrc + 2 * tap_stride, wr2);
+        if (KS == 3) {
+            w_load1(wsrc + tap_stride, wr1);
+            w_load1(wsrc + 2 * tap_stride, wr2);
+        }
     };
     auto w_store1 = [&](char* dst, const uint4 (&wr)[W_PER]) {
 #pragma unroll
@@ -438,8 +444,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     auto w_store = [&](int slot) {
         char* dst = wring + slot * W_BYTES;
         w_store1(dst, wr0);
-        w_store1(dst + W_TAP_BYTES, wr1);
-        w_store1(dst + 2 * W_TAP_BYTES, wr2);
+        if (KS == 3) {
+            w_store1(dst + W_TAP_BYTES, wr1);
+            w_store1(dst + 2 * W_TAP_BYTES, wr2);
+        }
     };
 
     float4v acc[WCO][WPX];
@@ -530,11 +538,32 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         ELVIS_BARRIER();                                                                               \
     }
     for (int kc = 0; kc < nkc; ++kc) {
-        const int r0 = kc * 3;
+        const int r0 = kc * KS;
         const int kcn = kc + 1 < nkc ? kc + 1 : kc;   // last chunk re-stages itself into the idle buffer
-        ELVIS_ROW_STEP(0)
-        ELVIS_ROW_STEP(1)
-        ELVIS_ROW_STEP(2)
+        if constexpr (KS == 3) {
+            ELVIS_ROW_STEP(0)
+            ELVIS_ROW_STEP(1)
+            ELVIS_ROW_STEP(2)
+        } else {
+            // 1x1: one tap per chunk; weight slot kc % 3 (runtime), whole tile staged in one phase
+            const int slot = kc % 3;
+            w_store((kc + 1) % 3);
+            w_load(kc + 2);
+            halo_load(kcn, 0, H_PER);
+            const char* ws = wring + slot * W_BYTES + a_off;
+            frag_t fa[WCO];
+#pragma unroll
+            for (int i = 0; i < WCO; ++i) fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 1024);
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) {
+                const int C = (j >> 1) * HX + (j & 1) * 16;
+                frag_t fb = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);
+            }
+            halo_store(kcn, (kc + 1) & 1, 0, H_PER);
+            __syncthreads();
+        }
         const int delta = (kc & 1) ? -HALO_BYTES : HALO_BYTES;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -634,7 +663,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 }
             }
         __syncthreads();
-        if (tid < TCO && co0 + tid < p.cout) {
+        if (tid < TCO && co0 + tid < p.cout) {   // TCO <= 128 < NT
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < NW_PX; ++w) {
@@ -661,13 +690,16 @@ inline TileCfg choose_tile(int cout) {
 }
 // the halo kernel handles 3x3 / stride 1 / pad 1 with a 128- or 64-channel output tile
 inline bool halo_eligible(const elvis_conv_desc* d) {
-    return d->ksize == 3 && d->stride == 1 && d->pad_before == 1 && d->cout >= 64 &&
-           d->ho == (d->upsample ? 2 * d->h : d->h) && d->wo == (d->upsample ? 2 * d->w : d->w);
+    bool same = d->ho == (d->upsample ? 2 * d->h : d->h) && d->wo == (d->upsample ? 2 * d->w : d->w);
+    if (d->ksize == 3) return d->stride == 1 && d->pad_before == 1 && same;
+    return d->ksize == 1 && d->stride == 1 && d->pad_before == 0 && same && !d->prologue &&
+           (long long)d->n * d->ho * d->wo >= 4096;   // tiny GEMMs (load-time embeddings) stay on the generic kernel
 }
 // 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
 // (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
 constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TX = 32;
-inline int halo_ty(int prologue) { return prologue ? HALO_TY_PRO : HALO_TY; }
+// 1x1 convs are HBM/latency-bound: the 8-row tile halves LDS and registers so two workgroups fit a CU
+inline int halo_ty(int prologue, int ksize = 3) { return (prologue || ksize == 1) ? HALO_TY_PRO : HALO_TY; }
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
 
 int validate(const elvis_conv_desc* d) {
@@ -703,15 +735,15 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return ELVIS_OK;
 }
 
-template <typename T, int TCO, bool PRO> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 512;
-    constexpr int TY = PRO ? HALO_TY_PRO : HALO_TY;
-    const size_t lds_fixed = 2 * (size_t)((TY + 2) * (HALO_TX + 2) * 64) + 9 * (size_t)TCO * 64;
+    constexpr int TY = (PRO || KS == 1) ? HALO_TY_PRO : HALO_TY;
+    const size_t lds_fixed = 2 * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + 3 * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -721,13 +753,14 @@ template <typename T, int TCO, bool PRO> int launch_halo_p(const ConvArgs& a, hi
     }
     long long nblk = (long long)a.n_co_tiles * a.tiles_x * a.tiles_y * a.n;
     ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_conv2d(halo)");
     return ELVIS_OK;
 }
 
 template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
-    return a.prologue ? launch_halo_p<T, TCO, true>(a, stream) : launch_halo_p<T, TCO, false>(a, stream);
+    if (a.ksize == 1) return launch_halo_p<T, TCO, false, 1>(a, stream);
+    return a.prologue ? launch_halo_p<T, TCO, true, 3>(a, stream) : launch_halo_p<T, TCO, false, 3>(a, stream);
 }
 
 template <typename T> int dispatch(const ConvArgs& a, int id, hipStream_t stream) {
@@ -799,7 +832,7 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
 
 extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     if (!d || !halo_eligible(d)) return 0;
-    int ty = halo_ty(d->prologue);
+    int ty = halo_ty(d->prologue, d->ksize);
     return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
 }
 
@@ -828,12 +861,24 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.n_px_tiles = (a.M + t.tpx - 1) / t.tpx;
     a.stats = stats;
     a.tiles_x = (d->wo + HALO_TX - 1) / HALO_TX;
-    a.tiles_y = (d->ho + halo_ty(d->prologue) - 1) / halo_ty(d->prologue);
+    a.tiles_y = (d->ho + halo_ty(d->prologue, d->ksize) - 1) / halo_ty(d->prologue, d->ksize);
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
-        if (d->dtype == ELVIS_F16)
-            return t.tco == 128 ? launch_halo<half_t, 128>(a, (hipStream_t)stream) : launch_halo<half_t, 64>(a, (hipStream_t)stream);
-        return t.tco == 128 ? launch_halo<float, 128>(a, (hipStream_t)stream) : launch_halo<float, 64>(a, (hipStream_t)stream);
+        hipStream_t st = (hipStream_t)stream;
+        if (d->dtype == ELVIS_F16) {
+            switch (t.tco) {
+                case 128: return launch_halo<half_t, 128>(a, st);
+                case 64: return launch_halo<half_t, 64>(a, st);
+                case 32: return launch_halo<half_t, 32>(a, st);
+                default: return launch_halo<half_t, 16>(a, st);
+            }
+        }
+        switch (t.tco) {
+            case 128: return launch_halo<float, 128>(a, st);
+            case 64: return launch_halo<float, 64>(a, st);
+            case 32: return launch_halo<float, 32>(a, st);
+            default: return launch_halo<float, 16>(a, st);
+        }
     }
     ELVIS_REQUIRE(!stats, "elvis_conv2d: fused statistics need a 3x3/stride-1 conv with cout >= 64 (query elvis_conv_stats_tiles)");
     if (d->dtype == ELVIS_F16) return dispatch<half_t>(a, t.id, (hipStream_t)stream);

@@ -222,7 +222,7 @@ class PackedConv:
         if prof is not None:
             e1.record()
             flops = 2.0 * self.ksize * self.ksize * (self.cin + self.cin2) * self.cout * x.n * ho * wo
-            prof.append((conv_kernel_name(self.cout, x.dtype_code, tiles > 0, prologue is not None), flops, e0, e1))
+            prof.append((conv_kernel_name(self.cout, x.dtype_code, tiles > 0, prologue is not None, self.ksize), flops, e0, e1))
         return out
 
 
@@ -231,14 +231,15 @@ class PackedConv:
 CONV_PROFILER = None
 
 
-def conv_kernel_name(cout: int, dtype_code: int, halo: bool, prologue: bool = False) -> str:
+def conv_kernel_name(cout: int, dtype_code: int, halo: bool, prologue: bool = False, ksize: int = 3) -> str:
     """Name of the kernel instantiation `elvis_conv2d` dispatches to (conv.hip choose_tile /
     halo_eligible): conv3x3_halo_kernel<T,TCO,NT,TY,PRO> or conv_igemm_kernel<T,WCO,WPX,NW_CO,NW_PX>
     - the same template arguments rocprofv3's kernel names carry."""
     t = "half" if dtype_code == L.F16 else "float"
     if halo:
-        return (f"conv3x3_halo_kernel<{t},{128 if cout % 128 == 0 else 64},512,"
-                f"{8 if prologue else 16},{'true' if prologue else 'false'}>")
+        tco = 128 if cout % 128 == 0 else (64 if cout >= 64 else (16 if cout <= 16 else 32))
+        return (f"conv3x3_halo_kernel<{t},{tco},512,"
+                f"{8 if (prologue or ksize == 1) else 16},{'true' if prologue else 'false'},{ksize}>")
     if cout % 128 == 0:
         return f"conv_igemm_kernel<{t},4,4,2,2>"
     if cout >= 64:

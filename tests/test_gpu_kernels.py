@@ -99,6 +99,8 @@ def test_conv_concat_residual_act_prologue(gpu_device, dtype):
     (160, 0, 160, 16, 64, False),     # cout padded 160 -> 192
     (64, 0, 128, 13, 21, True),       # fused nearest-2x upsample
     (3, 0, 64, 9, 33, False),         # cin < one K chunk
+    (128, 0, 3, 21, 40, False),       # conv_out-style: 16-channel output tile, cout = 3
+    (64, 0, 32, 17, 35, False),       # 32-channel output tile
 ])
 def test_conv_halo_fused(gpu_device, dtype, cfg):
     """The halo kernel with everything fused: GN-affine+SiLU prologue, bias, residual, and the
@@ -149,6 +151,47 @@ def test_conv_halo_fused(gpu_device, dtype, cfg):
     finally:
         del os.environ["ELVIS_NO_HALO"]
     assert (_nchw(y0) - got).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [
+    # c1, c2, cout, h, w, act   (1x1 / linear through the tile-staging kernel: n*h*w >= 4096)
+    (192, 0, 576, 40, 72, 0),
+    (192, 0, 768, 33, 70, 1),     # GELU epilogue
+    (256, 0, 128, 48, 64, 0),     # nin_shortcut
+    (320, 160, 160, 40, 64, 0),   # skip_connection on a virtual concat, cout padded 160 -> 192
+    (768, 0, 192, 32, 64, 0),
+    (3, 0, 3, 64, 64, 0),         # quant_conv-style
+])
+def test_conv_1x1_tiled(gpu_device, dtype, cfg):
+    from elvis_amd import ops
+    c1, c2, cout, h, w, act = cfg
+    g = torch.Generator().manual_seed(13)
+    n = 2
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
+    ctot = c1 + c2
+    wt = torch.randn(cout, ctot, 1, 1, generator=g) / math.sqrt(ctot)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g)
+    conv = ops.PackedConv(wt, b, dtype, gpu_device, c1, c2)
+    a1 = _act(x1, dtype, gpu_device)
+    a2 = _act(x2, dtype, gpu_device) if c2 else None
+    ar = _act(res, dtype, gpu_device)
+    y = conv(a1, a2, act=act, residual=ar, want_stats=True)
+    assert y.stats is not None
+    xcat = (torch.cat([x1, x2], 1) if c2 else x1).to(dtype).float()
+    ref = F.conv2d(xcat, wt.to(dtype).float(), b)
+    if act == 1:
+        ref = F.gelu(ref)
+    ref = ref + res.to(dtype).float()
+    got = _nchw(y)
+    assert (got - ref).abs().max().item() < TOL[dtype]
+    sums = torch.zeros((n, cout, 2), dtype=torch.float64, device=gpu_device)
+    from elvis_amd._lib import lib, check, ptr
+    check(lib().elvis_gn_partials_to_sums(ptr(y.stats), y.stats.shape[0] // n, n, cout, ptr(sums), cout, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+    assert torch.allclose(sums.cpu()[:, :, 0], got.double().sum((2, 3)), rtol=1e-5, atol=1e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
