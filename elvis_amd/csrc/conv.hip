@@ -89,6 +89,26 @@ template <> __device__ __forceinline__ uint4 prologue_apply<half_t>(uint4 v, con
     return v;
 }
 
+// Half-vector (8-byte) forms: the halo kernel spreads the prologue over the MFMA taps in pieces.
+__device__ __forceinline__ uint2 prologue_apply_half(uint2 v, const float (&pa)[2], const float (&pb)[2], float) {
+    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float t = fmaf(f[i], pa[i], pb[i]);
+        f[i] = t / (1.0f + expf(-t));
+    }
+    return v;
+}
+__device__ __forceinline__ uint2 prologue_apply_half(uint2 v, const float (&pa)[4], const float (&pb)[4], half_t) {
+    half_t* hv = reinterpret_cast<half_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float t = fmaf((float)hv[i], pa[i], pb[i]);
+        hv[i] = (half_t)(t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)));
+    }
+    return v;
+}
+
 // WCO/WPX: 16x16 sub-tiles per wave along co / px.  NW_CO x NW_PX waves per workgroup.
 template <typename T, int WCO, int WPX, int NW_CO, int NW_PX>
 __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs p) {
@@ -415,6 +435,33 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 *reinterpret_cast<uint4*>(dst + lds_row_off(chunk >> 2, chunk & 3)) = v;
         }
     };
+    // Fine-grained prologue (PRO, 3x3): one half of one staged 16-byte slot at a time, so the SiLU
+    // VALU work can be spread between the MFMAs of six taps instead of forming one serial block.
+    auto halo_act = [&](int kc, int slot, int half) {
+        constexpr int HV = VEC / 2;
+        const float* tp = ptab + (kc * 4 + q4) * 2 * VEC + half * HV;
+        float a[HV], b[HV];
+#pragma unroll
+        for (int e = 0; e < HV; e += 2) {
+            float2 a2 = *reinterpret_cast<const float2*>(tp + e);
+            float2 b2 = *reinterpret_cast<const float2*>(tp + VEC + e);
+            a[e] = a2.x; a[e + 1] = a2.y; b[e] = b2.x; b[e + 1] = b2.y;
+        }
+        uint2 v = half ? make_uint2(hreg[slot].z, hreg[slot].w) : make_uint2(hreg[slot].x, hreg[slot].y);
+        v = prologue_apply_half(v, a, b, T());
+        if (half) { hreg[slot].z = v.x; hreg[slot].w = v.y; } else { hreg[slot].x = v.x; hreg[slot].y = v.y; }
+    };
+    auto halo_write = [&](int kc, int buf, int slot) {
+        const bool second = kc >= p.nkc1;
+        const int pitch = second ? p.cin2_pitch : p.cin_pitch;
+        const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+        const bool keep = c0 < pitch && ((h_ok >> slot) & 1u);
+        uint4 v = hreg[slot];
+        v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+        int chunk = tid + slot * NT;
+        if ((slot + 1) * NT <= HCH || chunk < HCH)
+            *reinterpret_cast<uint4*>(halo + buf * HALO_BYTES + lds_row_off(chunk >> 2, chunk & 3)) = v;
+    };
     // row step r = kc*3 + dy: the three taps (dy, 0..2) of K chunk kc
     auto w_load1 = [&](const char* wsrc, uint4 (&wr)[W_PER]) {
 #pragma unroll
@@ -520,8 +567,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     {                                                                                                  \
         ELVIS_STAGE(w_store((DY + 1) % 3);)                                                            \
         ELVIS_STAGE(w_load(r0 + DY + 2);)                                                              \
-        ELVIS_STAGE(if (DY == 0) halo_load(kcn, 0, HA);)                                               \
-        ELVIS_STAGE(if (DY == 1) halo_load(kcn, HA, H_PER);)                                           \
+        ELVIS_STAGE(if (DY == 0) halo_load(kcn, 0, PRO ? H_PER : HA);)                                 \
+        ELVIS_STAGE(if (DY == 1 && !PRO) halo_load(kcn, HA, H_PER);)                                   \
         _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                             \
             const char* ws = wring + DY * W_BYTES + dx * W_TAP_BYTES + a_off;                          \
             frag_t fa[WCO];                                                                            \
@@ -531,10 +578,25 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 const int C = ((j >> 1) + DY) * HX + (j & 1) * 16 + dx;                                \
                 frag_t fb = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64); \
                 _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);        \
+                /* PRO: this tap's share of the next chunk's prologue, placed mid-tap */               \
+                if (PRO && DY >= 1 && j == WPX / 2 - 1) {                                              \
+                    _Pragma("unroll") for (int pi = 0; pi < 2 * H_PER; ++pi)                           \
+                        if (pi * 6 / (2 * H_PER) == (DY - 1) * 3 + dx) {                               \
+                            ELVIS_STAGE(halo_act(kcn, pi / 2, pi & 1);)                                \
+                            if (pi & 1) { ELVIS_STAGE(halo_write(kcn, (kc + 1) & 1, pi / 2);) }        \
+                        }                                                                              \
+                }                                                                                      \
+            }                                                                                          \
+            /* interleave the prologue VALU with this tap's MFMAs (1 MFMA : 3 VALU) */                \
+            if (PRO && DY >= 1) {                                                                      \
+                _Pragma("unroll") for (int g = 0; g < WCO * WPX; ++g) {                                \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                 \
+                }                                                                                      \
             }                                                                                          \
         }                                                                                              \
-        ELVIS_STAGE(if (DY == 0) halo_store(kcn, (kc + 1) & 1, 0, HA);)                                \
-        ELVIS_STAGE(if (DY == 1) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)                            \
+        ELVIS_STAGE(if (DY == 0 && !PRO) halo_store(kcn, (kc + 1) & 1, 0, HA);)                        \
+        ELVIS_STAGE(if (DY == 1 && !PRO) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)                    \
         ELVIS_BARRIER();                                                                               \
     }
     for (int kc = 0; kc < nkc; ++kc) {
