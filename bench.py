@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mode", choices=["f16", "f32"], default="f16")
     ap.add_argument("--no-fuse-gn", dest="fuse_gn", action="store_false",
                     help="run GroupNorm-apply+SiLU as separate elementwise passes instead of the conv prologue")
+    ap.add_argument("--batch", type=int, default=1, help="frames per network invocation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -143,7 +144,8 @@ def main():
     gathered = torch.empty((world * F, H, W, 3), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
-        restore.restore_clip_single4x_device(model, frames_d, levels_d, B, gidx, noise=noise_d, out=out_d)
+        restore.restore_clip_single4x_device(model, frames_d, levels_d, B, gidx, noise=noise_d, out=out_d,
+                                             batch=args.batch)
         if world > 1:
             dist.all_gather_into_tensor(gathered, out_d)
 
@@ -203,7 +205,7 @@ def main():
             "config": {"workload": f"{F}-frame {W}x{H} synthetic clip per GPU, ELVIS v2 Downsample (SinSR 4x), "
                                    f"block {B}, levels 0-3, weights seed 0 (random init), quantize=True",
                        "frames_per_gpu": F, "parallelism": f"frame-sharded x{world}, 1 all-gather" if world > 1 else "single GPU",
-                       "gn_fused_into_conv": bool(args.fuse_gn)},
+                       "gn_fused_into_conv": bool(args.fuse_gn), "frames_per_invocation": args.batch},
             "roofline": roof, "cpu_baseline": cpu_base, "parity": parity,
         }
         print(json.dumps(line))

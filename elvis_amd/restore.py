@@ -88,11 +88,14 @@ def get_sinsr_upsample_fn(device, *, scale: int = 2, seed: int = DEFAULT_SEED, f
 
 def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, levels_d: torch.Tensor, block_size: int,
                                  frame_indices: Sequence[int], seed: int = DEFAULT_SEED, swap_rb: bool = True,
-                                 noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                 noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                                 batch: int = 1) -> torch.Tensor:
     """The north-star Downsample path, fully on device: whole frame /4 (INTER_AREA, elvis.py:2565)
     -> ONE SinSR 4x call (README.md:50) -> final-stage paste of elvis.py:2584-2595 at f=1
     (`level == 0 ? decoded frame : SR`).  Frames whose map is all zero skip the network.
-    `noise` ([n,3,Hp,Wp] f32, resident) may be passed to keep host RNG out of a timed region."""
+    `noise` ([n,3,Hp,Wp] f32, resident) may be passed to keep host RNG out of a timed region.
+    `batch` frames go through the network together (fills the GPU better on the UNet's small
+    levels; results are identical - every op is per-sample)."""
     n, H, W, _ = frames_d.shape
     if H % 4 or W % 4 or H % block_size or W % block_size:
         raise ValueError("Image dimensions must be divisible by block_size and by 4.")
@@ -100,15 +103,26 @@ def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, leve
         out = torch.empty_like(frames_d)
     active = (levels_d > 0).flatten(1).any(dim=1).tolist()
     with torch.cuda.device(model.device):
+        todo = [i for i in range(n) if active[i]]
         for i in range(n):
-            f = frames_d[i:i + 1]
             if not active[i]:
-                out[i:i + 1] = f
-                continue
+                out[i:i + 1] = frames_d[i:i + 1]
+        for s0 in range(0, len(todo), max(1, batch)):
+            idx = todo[s0:s0 + max(1, batch)]
+            contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+            sel = slice(idx[0], idx[0] + len(idx)) if contiguous else torch.tensor(idx, device=frames_d.device)
+            f = frames_d[sel] if contiguous else frames_d[sel].contiguous()
+            lv = levels_d[sel] if contiguous else levels_d[sel].contiguous()
             lr = ops.area_downscale_u8(f, 4)
-            nz = noise[i:i + 1] if noise is not None else model.make_noise(seed, [frame_indices[i]], H // 4, W // 4)
+            if noise is not None:
+                nz = noise[sel] if contiguous else noise[sel].contiguous()
+            else:
+                nz = model.make_noise(seed, [frame_indices[i] for i in idx], H // 4, W // 4)
             sr = model.forward(lr, nz, swap_rb=swap_rb)
-            ops.recompose_u8(f, sr, levels_d[i:i + 1], block_size, 0, out=out[i:i + 1])
+            if contiguous:
+                ops.recompose_u8(f, sr, lv, block_size, 0, out=out[sel])
+            else:
+                out[sel] = ops.recompose_u8(f, sr, lv, block_size, 0)
     return out
 
 
