@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--mode", choices=["f16", "f32"], default="f16")
     ap.add_argument("--no-fuse-gn", dest="fuse_gn", action="store_false",
                     help="run GroupNorm-apply+SiLU as separate elementwise passes instead of the conv prologue")
-    ap.add_argument("--batch", type=int, default=1, help="frames per network invocation")
+    ap.add_argument("--batch", type=int, default=6, help="frames per network invocation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()

@@ -506,6 +506,39 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     const int lane_off = lds_row_off(lane & 15, lane >> 4);
     const int lq = lane >> 4, lr = lane & 15;
 
+    // With no epilogue activation, y = conv + bias + residual: start the accumulators from
+    // bias + residual so the residual's HBM latency hides under the start-up instead of sitting
+    // on the epilogue's critical path.
+    const bool fold = p.act == 0;
+    if (fold && (p.res || p.bias)) {
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+            const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
+            const bool pix_ok = oy < p.ho && ox < p.wo;
+            const long long m = ((long long)nimg * p.ho + oy) * p.wo + ox;
+#pragma unroll
+            for (int i = 0; i < WCO; ++i) {
+                const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
+                if (!pix_ok || co >= p.cout) continue;
+                const int nv = p.cout - co < 4 ? p.cout - co : 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = 0.f;
+                    if (r < nv) {
+                        if (p.bias) v = p.bias[co + r];
+                        if (p.res) v += to_f(((const T*)p.res)[m * p.res_pitch + co + r]);
+                    }
+                    acc[i][j][r] = v;
+                }
+            }
+        }
+    }
+
+    // ---- prologue: halo(0) and weight row 0 into LDS; weight row 1 in flight in registers.
+    // The first global loads are issued before the prologue table is built so their latency
+    // overlaps it (one workgroup per CU: nothing else hides a workgroup's start-up).
+    halo_load(0, 0, H_PER);
+    w_load(0);
     if (PRO) {
         // table entry t = (kc*4 + q)*2*VEC + {0..VEC-1: a, VEC..2VEC-1: b}; channels past the
         // logical count get a = b = 0 (silu(0) = 0 keeps zero padding exact)
@@ -522,9 +555,6 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         }
         __syncthreads();
     }
-    // ---- prologue: halo(0) and weight row 0 into LDS; weight row 1 in flight in registers
-    halo_load(0, 0, H_PER);
-    w_load(0);
     halo_store(0, 0, 0, H_PER);
     w_store(0);
     w_load(1);
@@ -653,7 +683,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             if (!pix_ok || co >= p.cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             const int nv = p.cout - co < 4 ? p.cout - co : 4;
-            if (p.bias) {
+            if (p.bias && !fold) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (r < nv) v[r] += p.bias[co + r];
@@ -665,7 +695,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
             }
-            if (p.res) {
+            if (p.res && !fold) {
                 const T* rp = (const T*)p.res + m * p.res_pitch + co;
                 if (nv == 4) {
                     if constexpr (sizeof(T) == 2) {
