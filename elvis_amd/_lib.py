@@ -48,7 +48,8 @@ SIGNATURES = {
     "elvis_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp],
     "elvis_conv_stats_tiles": [C.POINTER(ConvDesc)],
     "elvis_gn_partials_to_sums": [vp, i32, i32, i32, vp, i32, i32, vp],
-    "elvis_groupnorm_sums": [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp],
+    "elvis_groupnorm_workspace_floats": [i32, i32, i32, i32],
+    "elvis_groupnorm_sums": [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp],
     "elvis_groupnorm_affine": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "elvis_affine_act": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "elvis_layernorm": [vp, vp, i32, i64, i32, i32, i32, vp, vp, f32, vp],
@@ -85,6 +86,7 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         handle.elvis_last_error.restype = C.c_char_p
         handle.elvis_conv_packed_weight_bytes.restype = C.c_size_t
+        handle.elvis_groupnorm_workspace_floats.restype = C.c_size_t
         if handle.elvis_abi_version() != 1:
             raise RuntimeError("libelvis_amd.so ABI version mismatch")
         _lib = handle

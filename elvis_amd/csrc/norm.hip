@@ -15,7 +15,7 @@ template <typename T> struct Vec16 {
 // pixels  plane + k*PL  of its slab (PL = 256 / CV pixel lanes; the remaining threads idle).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_channel_sums_kernel(const T* __restrict__ x, int hw, int c, int pitch,
-                                                              int px_per_block, double* __restrict__ sums, int ctot, int coff) {
+                                                              int px_per_block, float* __restrict__ partials) {
     constexpr int VEC = DT<T>::VEC;
     extern __shared__ float red[];  // [PL][c][2]
     const int cv = (c + VEC - 1) / VEC;
@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void gn_channel_sums_kernel(const T* __restric
             a += red[(pl * c + ch) * 2 + 0];
             b += red[(pl * c + ch) * 2 + 1];
         }
-        atomicAdd(&sums[((long long)n * ctot + coff + ch) * 2 + 0], (double)a);
-        atomicAdd(&sums[((long long)n * ctot + coff + ch) * 2 + 1], (double)b);
+        // one partial row per workgroup, reduced afterwards in a fixed order (bit-reproducible)
+        float* dst = partials + (((long long)n * gridDim.x + blockIdx.x) * c + ch) * 2;
+        dst[0] = a;
+        dst[1] = b;
     }
 }
 
@@ -199,30 +201,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 }  // namespace
 
+static int gn_blocks(int dtype, int hw, int c, int* px_per_block_out) {
+    int vec = dtype == ELVIS_F16 ? 8 : 4;
+    int cv = (c + vec - 1) / vec;
+    int pl = 256 / (cv > 0 ? cv : 1);
+    if (pl < 1) pl = 1;
+    // ~2048 workgroups over the pixels, at least 16 pixels per lane-plane each
+    int px_per_block = (int)((hw + 2047) / 2048);
+    if (px_per_block < pl * 16) px_per_block = pl * 16;
+    if (px_per_block_out) *px_per_block_out = px_per_block;
+    return (hw + px_per_block - 1) / px_per_block;
+}
+
+extern "C" size_t elvis_groupnorm_workspace_floats(int dtype, int n, int hw, int c) {
+    if (n <= 0 || hw <= 0 || c <= 0) return 0;
+    return (size_t)n * gn_blocks(dtype, hw, c, nullptr) * c * 2;
+}
+
 extern "C" int elvis_groupnorm_sums(const void* x, int dtype, int n, int hw, int c, int pitch, double* sums,
-                                    int sums_ctot, int sums_coff, elvis_stream_t stream) {
-    ELVIS_REQUIRE(x && sums, "elvis_groupnorm_sums: null pointer");
+                                    int sums_ctot, int sums_coff, float* workspace, elvis_stream_t stream) {
+    ELVIS_REQUIRE(x && sums && workspace, "elvis_groupnorm_sums: null pointer");
     ELVIS_REQUIRE(n > 0 && hw > 0 && c > 0 && pitch >= c && pitch % 8 == 0, "elvis_groupnorm_sums: bad shape c=%d pitch=%d", c, pitch);
     int vec = dtype == ELVIS_F16 ? 8 : 4;
     int cv = (c + vec - 1) / vec;
     ELVIS_REQUIRE(cv <= 256, "elvis_groupnorm_sums: too many channels (%d)", c);
     ELVIS_REQUIRE(sums_coff >= 0 && sums_coff + c <= sums_ctot, "elvis_groupnorm_sums: channel slice [%d,%d) outside %d", sums_coff, sums_coff + c, sums_ctot);
     int pl = 256 / cv;
-    // ~2048 workgroups over the pixels, at least 64 pixels per lane-plane each
-    int px_per_block = (int)((hw + 2047) / 2048);
-    if (px_per_block < pl * 16) px_per_block = pl * 16;
-    int gx = (hw + px_per_block - 1) / px_per_block;
+    int px_per_block = 0;
+    int gx = gn_blocks(dtype, hw, c, &px_per_block);
     size_t lds = (size_t)pl * c * 2 * sizeof(float);
     ELVIS_REQUIRE(lds <= 64 * 1024, "elvis_groupnorm_sums: LDS budget exceeded");
     if (dtype == ELVIS_F16)
         hipLaunchKernelGGL(gn_channel_sums_kernel<half_t>, dim3(gx, n), dim3(256), lds, (hipStream_t)stream,
-                           (const half_t*)x, hw, c, pitch, px_per_block, sums, sums_ctot, sums_coff);
+                           (const half_t*)x, hw, c, pitch, px_per_block, workspace);
     else if (dtype == ELVIS_F32)
         hipLaunchKernelGGL(gn_channel_sums_kernel<float>, dim3(gx, n), dim3(256), lds, (hipStream_t)stream,
-                           (const float*)x, hw, c, pitch, px_per_block, sums, sums_ctot, sums_coff);
+                           (const float*)x, hw, c, pitch, px_per_block, workspace);
     else
         ELVIS_REQUIRE(false, "elvis_groupnorm_sums: bad dtype");
     ELVIS_CHECK_LAUNCH("elvis_groupnorm_sums");
+    hipLaunchKernelGGL(gn_partials_reduce_kernel, dim3(c, n), dim3(256), 0, (hipStream_t)stream, workspace, gx, c, sums,
+                       sums_ctot, sums_coff);
+    ELVIS_CHECK_LAUNCH("elvis_groupnorm_sums(reduce)");
     return ELVIS_OK;
 }
 

@@ -256,15 +256,17 @@ def groupnorm_affine(xs, gamma, beta, groups, eps, scale=None, shift=None):
     n, hw = x0.n, x0.h * x0.w
     ctot = sum(x.c for x in xs)
     dev = x0.t.device
-    sums = torch.zeros((n, ctot, 2), dtype=torch.float64, device=dev)
+    sums = torch.empty((n, ctot, 2), dtype=torch.float64, device=dev)   # every entry is written below
     off = 0
     for x in xs:
         if x.stats is not None:   # fused: the producing conv already wrote per-tile partial sums
             check(lib().elvis_gn_partials_to_sums(ptr(x.stats), x.stats.shape[0] // n, n, x.c, ptr(sums), ctot, off,
                                                   _s(x.t)), dev)
         else:
+            nws = lib().elvis_groupnorm_workspace_floats(x.dtype_code, n, hw, x.c)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
             check(lib().elvis_groupnorm_sums(ptr(x.t), x.dtype_code, n, hw, x.c, x.pitch, ptr(sums), ctot, off,
-                                             _s(x.t)), dev)
+                                             ptr(ws), _s(x.t)), dev)
         off += x.c
     pa = torch.empty((n, ctot), dtype=torch.float32, device=dev)
     pb = torch.empty((n, ctot), dtype=torch.float32, device=dev)

@@ -157,12 +157,14 @@ int elvis_conv_stats_tiles(const elvis_conv_desc* d);
 int elvis_gn_partials_to_sums(const float* partials, int tiles_per_image, int n, int c, double* sums,
                               int sums_ctot, int sums_coff, elvis_stream_t stream);
 
-/* GroupNorm statistics: per-(n,channel) sum and sum of squares, sums[n, sums_ctot, 2] f64
- * (f32 partials per workgroup, one f64 atomic per channel per workgroup).  The tensor's channels
- * land at [sums_coff, sums_coff+c) so a virtual concat of two tensors shares one buffer.
- * `sums` must be zeroed by the caller. */
+/* GroupNorm statistics of a tensor that has no fused statistics: per-(n,channel) sum and sum of
+ * squares into sums[n, sums_ctot, 2] f64 at channels [sums_coff, sums_coff+c) (a virtual concat of
+ * two tensors shares one buffer).  One partial row per workgroup is written to `workspace`
+ * (elvis_groupnorm_workspace_floats(...) floats) and reduced in a fixed order: bit-reproducible,
+ * no atomics. */
+size_t elvis_groupnorm_workspace_floats(int dtype, int n, int hw, int c);
 int elvis_groupnorm_sums(const void* x, int dtype, int n, int hw, int c, int pitch, double* sums,
-                         int sums_ctot, int sums_coff, elvis_stream_t stream);
+                         int sums_ctot, int sums_coff, float* workspace, elvis_stream_t stream);
 
 /* Turn sums into per-(n,channel) affine pa,pb so that GN(x)*(1+scale)+shift == x*pa+pb.
  * gamma,beta f32[c]; scale,shift f32[c] may be NULL (then 0). */
