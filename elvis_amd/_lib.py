@@ -27,7 +27,7 @@ vp, i32, f32, i64 = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "n", "h", "w", "cin", "cin_pitch", "cin2", "cin2_pitch", "cout", "cout_pitch",
-        "ksize", "stride", "pad_before", "upsample", "ho", "wo", "act", "prologue")]
+        "ksize", "stride", "pad_before", "upsample", "ho", "wo", "act", "prologue", "subpixel")]
 
 
 # name -> argtypes (every symbol include/elvis_amd.h declares; checked by tests/test_cabi.py)

@@ -45,6 +45,7 @@ struct ConvArgs {
     // halo kernel only
     float* stats;         // [n*tiles_y*tiles_x][cout][2] partial (sum, sumsq) or null
     int tiles_x, tiles_y;
+    int sub, par_a, par_b;   // sub-pixel mode (KS == 2): output pixel (2y+par_a, 2x+par_b)
 };
 
 template <typename T> struct Frag;
@@ -320,8 +321,12 @@ template <typename T, int TCO, int NT, int TY, bool PRO, int KS = 3>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     // KS = 3: 3x3 / pad 1 (halo of one pixel).  KS = 1: 1x1 conv / linear layer - the same staging
     // pipeline with no halo and one tap per K chunk (HBM-bound: what matters is bytes in flight).
-    constexpr int PADH = KS / 2;
-    constexpr int TX = 32, HX = TX + 2 * PADH, HY = TY + 2 * PADH, HP = HX * HY;
+    // KS = 2: one parity of the sub-pixel decomposition of "nearest-2x upsample + 3x3 conv": the 3x3
+    // kernel on the upsampled grid collapses to a 2x2 kernel (pre-summed weights) on the low-res
+    // grid for each output parity (a,b), 16 instead of 36 taps per low-res pixel (2.25x fewer FLOPs);
+    // top/left padding is 1-a / 1-b and the tile writes output pixels (2y+a, 2x+b).
+    constexpr int TX = 32, HX = TX + KS - 1, HY = TY + KS - 1, HP = HX * HY;
+    constexpr int NSLOT = KS == 2 ? 2 : 3;   // weight ring slots; row step r uses slot r % NSLOT (static)
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
@@ -339,10 +344,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;                     // 2 buffers of HALO_BYTES
-    char* const wring = smem + 2 * HALO_BYTES;   // 3 slots of W_BYTES
+    char* const wring = smem + 2 * HALO_BYTES;   // NSLOT slots of W_BYTES
     // prologue table: per K chunk and 16-byte slice q, VEC x a then VEC x b (f32), so a thread's
     // GroupNorm affine for the slice it stages is two LDS vector reads - no long-lived registers
-    float* const ptab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + 3 * W_BYTES);
+    float* const ptab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NSLOT * W_BYTES);
 
     long long nblk = (long long)p.n_co_tiles * p.tiles_x * p.tiles_y * p.n;
     long long bid = blockIdx.x;
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     const int w_co = wave / NW_PX, w_px = wave % NW_PX;
     const int lh = p.upsample ? p.h * 2 : p.h, lw = p.upsample ? p.w_in * 2 : p.w_in;
 
+    const int pad_y = KS == 2 ? 1 - p.par_a : KS / 2, pad_x = KS == 2 ? 1 - p.par_b : KS / 2;
     // ---- halo staging plan: chunk = tid + NT*i -> (halo pixel, 16-byte channel slice q = tid&3).
     // Branch-free: out-of-image / out-of-range chunks load pixel 0 and are zeroed by a select, so
     // the compiler can keep counted (not vmcnt(0)) waits on the prefetch pipeline.
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         int chunk = tid + i * NT;
         int pix = chunk >> 2;
         int hy = pix / HX, hx = pix - hy * HX;
-        int gy = oy0 + hy - PADH, gx = ox0 + hx - PADH;
+        int gy = oy0 + hy - pad_y, gx = ox0 + hx - pad_x;
         bool ok = chunk < HCH && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
         int sy = p.upsample ? (gy >> 1) : gy, sx = p.upsample ? (gx >> 1) : gx;
         h_src[i] = ok ? (nimg * p.h + sy) * p.w_in + sx : 0;
@@ -476,10 +482,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         const long long tap_stride = (long long)nkc * p.co_pad * 64;
         const char* wsrc = (const char*)p.w + ((long long)(dy * KS * nkc + kc) * p.co_pad + co0) * 64;
         w_load1(wsrc, wr0);
-        if (KS == 3) {
-            w_load1(wsrc + tap_stride, wr1);
-            w_load1(wsrc + 2 * tap_stride, wr2);
-        }
+        if (KS >= 2) w_load1(wsrc + tap_stride, wr1);
+        if (KS == 3) w_load1(wsrc + 2 * tap_stride, wr2);
     };
     auto w_store1 = [&](char* dst, const uint4 (&wr)[W_PER]) {
 #pragma unroll
@@ -491,10 +495,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     auto w_store = [&](int slot) {
         char* dst = wring + slot * W_BYTES;
         w_store1(dst, wr0);
-        if (KS == 3) {
-            w_store1(dst + W_TAP_BYTES, wr1);
-            w_store1(dst + 2 * W_TAP_BYTES, wr2);
-        }
+        if (KS >= 2) w_store1(dst + W_TAP_BYTES, wr1);
+        if (KS == 3) w_store1(dst + 2 * W_TAP_BYTES, wr2);
     };
 
     float4v acc[WCO][WPX];
@@ -514,8 +516,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < WPX; ++j) {
             const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
-            const bool pix_ok = oy < p.ho && ox < p.wo;
-            const long long m = ((long long)nimg * p.ho + oy) * p.wo + ox;
+            const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
+            const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+                                        : ((long long)nimg * p.ho + oy) * p.wo + ox;
 #pragma unroll
             for (int i = 0; i < WCO; ++i) {
                 const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
@@ -595,11 +598,11 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #endif
 #define ELVIS_ROW_STEP(DY)                                                                             \
     {                                                                                                  \
-        ELVIS_STAGE(w_store((DY + 1) % 3);)                                                            \
+        ELVIS_STAGE(w_store((DY + 1) % NSLOT);)                                                        \
         ELVIS_STAGE(w_load(r0 + DY + 2);)                                                              \
         ELVIS_STAGE(if (DY == 0) halo_load(kcn, 0, PRO ? H_PER : HA);)                                 \
         ELVIS_STAGE(if (DY == 1 && !PRO) halo_load(kcn, HA, H_PER);)                                   \
-        _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                             \
+        _Pragma("unroll") for (int dx = 0; dx < KS; ++dx) {                                            \
             const char* ws = wring + DY * W_BYTES + dx * W_TAP_BYTES + a_off;                          \
             frag_t fa[WCO];                                                                            \
             _Pragma("unroll") for (int i = 0; i < WCO; ++i)                                            \
@@ -636,6 +639,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             ELVIS_ROW_STEP(0)
             ELVIS_ROW_STEP(1)
             ELVIS_ROW_STEP(2)
+        } else if constexpr (KS == 2) {
+            ELVIS_ROW_STEP(0)
+            ELVIS_ROW_STEP(1)
         } else {
             // 1x1: one tap per chunk; weight slot kc % 3 (runtime), whole tile staged in one phase
             const int slot = kc % 3;
@@ -675,8 +681,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
-        const bool pix_ok = oy < p.ho && ox < p.wo;
-        const long long m = ((long long)nimg * p.ho + oy) * p.wo + ox;
+        const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
+        const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+                                    : ((long long)nimg * p.ho + oy) * p.wo + ox;
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
             const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 a += red[(w * TCO + tid) * 2 + 0];
                 b += red[(w * TCO + tid) * 2 + 1];
             }
-            long long tile = ((long long)nimg * p.tiles_y + ty) * p.tiles_x + tx;
+            long long tile = ((long long)nimg * p.tiles_y + ty) * p.tiles_x + tx;   // (sub-pixel: p.stats is pre-offset per parity)
             float* dst = p.stats + (tile * p.cout + co0 + tid) * 2;
             dst[0] = a;
             dst[1] = b;
@@ -782,6 +789,7 @@ inline TileCfg choose_tile(int cout) {
 }
 // the halo kernel handles 3x3 / stride 1 / pad 1 with a 128- or 64-channel output tile
 inline bool halo_eligible(const elvis_conv_desc* d) {
+    if (d->ksize == 2) return true;   // validated: sub-pixel parity conv
     bool same = d->ho == (d->upsample ? 2 * d->h : d->h) && d->wo == (d->upsample ? 2 * d->w : d->w);
     if (d->ksize == 3) return d->stride == 1 && d->pad_before == 1 && same;
     return d->ksize == 1 && d->stride == 1 && d->pad_before == 0 && same && !d->prologue &&
@@ -799,7 +807,11 @@ int validate(const elvis_conv_desc* d) {
     ELVIS_REQUIRE(d->dtype == ELVIS_F32 || d->dtype == ELVIS_F16, "conv: bad dtype %d", d->dtype);
     ELVIS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->ho > 0 && d->wo > 0,
                   "conv: bad shape n=%d h=%d w=%d cin=%d cout=%d ho=%d wo=%d", d->n, d->h, d->w, d->cin, d->cout, d->ho, d->wo);
-    ELVIS_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize must be 1 or 3 (got %d)", d->ksize);
+    ELVIS_REQUIRE(d->ksize == 1 || d->ksize == 3 || (d->ksize == 2 && d->subpixel >= 1 && d->subpixel <= 4),
+                  "conv: ksize must be 1 or 3, or 2 with subpixel = 1 + parity (got ksize %d, subpixel %d)", d->ksize, d->subpixel);
+    if (d->ksize == 2)
+        ELVIS_REQUIRE(d->stride == 1 && !d->upsample && !d->prologue && d->ho == 2 * d->h && d->wo == 2 * d->w,
+                      "conv: a sub-pixel parity conv maps h x w to 2h x 2w, stride 1, no prologue");
     ELVIS_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2");
     ELVIS_REQUIRE(d->cin_pitch >= d->cin && d->cin_pitch % 8 == 0, "conv: cin_pitch %d must be >= cin %d and a multiple of 8", d->cin_pitch, d->cin);
     ELVIS_REQUIRE(d->cout_pitch >= d->cout && d->cout_pitch % 4 == 0, "conv: cout_pitch %d invalid for cout %d", d->cout_pitch, d->cout);
@@ -810,7 +822,8 @@ int validate(const elvis_conv_desc* d) {
     }
     int lh = d->upsample ? 2 * d->h : d->h, lw = d->upsample ? 2 * d->w : d->w;
     // last tap of the last output must start inside [-(pad), l+2): loose sanity bound
-    ELVIS_REQUIRE((long long)(d->ho - 1) * d->stride - d->pad_before < lh && (long long)(d->wo - 1) * d->stride - d->pad_before < lw,
+    ELVIS_REQUIRE(d->ksize == 2 ||
+                  ((long long)(d->ho - 1) * d->stride - d->pad_before < lh && (long long)(d->wo - 1) * d->stride - d->pad_before < lw),
                   "conv: output %dx%d does not fit input %dx%d (stride %d)", d->ho, d->wo, lh, lw, d->stride);
     return ELVIS_OK;
 }
@@ -830,7 +843,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 512;
     constexpr int TY = (PRO || KS == 1) ? HALO_TY_PRO : HALO_TY;
-    const size_t lds_fixed = 2 * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + 3 * KS * (size_t)TCO * 64;
+    const size_t lds_fixed = 2 * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + (KS == 2 ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
     static bool attr_set = false;
@@ -852,6 +865,7 @@ template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArg
 
 template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
     if (a.ksize == 1) return launch_halo_p<T, TCO, false, 1>(a, stream);
+    if (a.ksize == 2) return launch_halo_p<T, TCO, false, 2>(a, stream);
     return a.prologue ? launch_halo_p<T, TCO, true, 3>(a, stream) : launch_halo_p<T, TCO, false, 3>(a, stream);
 }
 
@@ -925,6 +939,7 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
 extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     if (!d || !halo_eligible(d)) return 0;
     int ty = halo_ty(d->prologue, d->ksize);
+    if (d->ksize == 2) return d->n * ((d->h + ty - 1) / ty) * ((d->w + HALO_TX - 1) / HALO_TX);   // per parity launch
     return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
 }
 
@@ -952,8 +967,11 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.n_co_tiles = a.co_pad / t.tco;
     a.n_px_tiles = (a.M + t.tpx - 1) / t.tpx;
     a.stats = stats;
-    a.tiles_x = (d->wo + HALO_TX - 1) / HALO_TX;
-    a.tiles_y = (d->ho + halo_ty(d->prologue, d->ksize) - 1) / halo_ty(d->prologue, d->ksize);
+    a.sub = d->ksize == 2;
+    a.par_a = d->ksize == 2 ? (d->subpixel - 1) >> 1 : 0;
+    a.par_b = d->ksize == 2 ? (d->subpixel - 1) & 1 : 0;
+    a.tiles_x = ((d->ksize == 2 ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
+    a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + halo_ty(d->prologue, d->ksize) - 1) / halo_ty(d->prologue, d->ksize);
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
         hipStream_t st = (hipStream_t)stream;

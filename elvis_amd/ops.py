@@ -175,6 +175,8 @@ class PackedConv:
         d.cin, d.cin_pitch, d.cin2, d.cin2_pitch = cin, pitch_for(cin), cin2, pitch_for(cin2) if cin2 else 0
         d.cout, d.cout_pitch = cout, pitch_for(cout)
         d.ksize, d.stride = kh, 1
+        if kh == 2:   # one parity of a sub-pixel upsample conv (PackedUpConv): h x w -> 2h x 2w
+            d.subpixel, d.ho, d.wo = 1, 2, 2
         nbytes = lib().elvis_conv_packed_weight_bytes(C.byref(d))
         w_dev = weight_oihw.to(device=device, dtype=torch.float32).contiguous()
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -247,6 +249,65 @@ def conv_kernel_name(cout: int, dtype_code: int, halo: bool, prologue: bool = Fa
     if cout <= 16:
         return f"conv_igemm_kernel<{t},1,4,1,4>"
     return f"conv_igemm_kernel<{t},2,4,1,4>"
+
+
+class PackedUpConv:
+    """`conv3x3(nearest_upsample_2x(x))` as four sub-pixel 2x2 convs on the low-res grid.
+
+    Output pixel (2y+a, 2x+b) sees, through the upsampled 3x3 window, only a 2x2 block of low-res
+    pixels: rows {y-1, y} for a=0 ({y, y+1} for a=1) and likewise for columns, with the 3x3 weights
+    that land on the same low-res pixel summed (rows 1+2 for a=0, rows 0+1 for a=1).  Exact in real
+    arithmetic; 16 instead of 36 taps per low-res pixel (2.25x fewer FLOPs).  Weights are summed in
+    fp32 at load time."""
+
+    ROWSETS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+
+    def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int):
+        cout, ctot, kh, kw = weight_oihw.shape
+        assert kh == 3 and kw == 3 and ctot == cin
+        self.cin, self.cout = cin, cout
+        w = weight_oihw.float()
+        self.par = []
+        for a in (0, 1):
+            for b in (0, 1):
+                w2 = torch.zeros(cout, cin, 2, 2)
+                for dyi, rows in enumerate(self.ROWSETS[a]):
+                    for dxi, cols in enumerate(self.ROWSETS[b]):
+                        w2[:, :, dyi, dxi] = sum(w[:, :, r, c] for r in rows for c in cols)
+                self.par.append(PackedConv(w2, bias, dtype, device, cin))
+
+    def __call__(self, x: Act, want_stats: bool = False) -> Act:
+        n, h, w = x.n, x.h, x.w
+        out = new_act(n, 2 * h, 2 * w, self.cout, x.t.dtype, x.t.device)
+        stats = None
+        for k, conv in enumerate(self.par):
+            d = ConvDesc()
+            d.dtype = x.dtype_code
+            d.n, d.h, d.w = n, h, w
+            d.cin, d.cin_pitch = x.c, x.pitch
+            d.ksize, d.stride, d.subpixel = 2, 1, 1 + k
+            d.ho, d.wo = 2 * h, 2 * w
+            d.cout, d.cout_pitch = self.cout, out.pitch
+            tiles = lib().elvis_conv_stats_tiles(C.byref(d))
+            if want_stats and stats is None:
+                stats = torch.empty((4 * tiles, self.cout, 2), dtype=torch.float32, device=x.t.device)
+            sp = stats[k * tiles:(k + 1) * tiles] if stats is not None else None
+            prof = CONV_PROFILER
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib().elvis_conv2d(C.byref(d), ptr(x.t), 0, ptr(conv.packed), ptr(conv.bias), 0, 0, 0, 0, ptr(out.t),
+                                     ptr(sp), _s(x.t)), x.t.device)
+            if prof is not None:
+                e1.record()
+                prof.append((conv_kernel_name(self.cout, x.dtype_code, True, False, 2),
+                             2.0 * 4 * self.cin * self.cout * n * h * w, e0, e1))
+        if stats is not None:
+            # per image the reduce expects that image's tiles contiguous: [parity][n*tiles] -> [n][4*tiles/n]
+            t_img = tiles // n
+            stats = stats.view(4, n, t_img, self.cout, 2).permute(1, 0, 2, 3, 4).reshape(4 * tiles, self.cout, 2).contiguous() if n > 1 else stats
+        out.stats = stats
+        return out
 
 
 def groupnorm_affine(xs, gamma, beta, groups, eps, scale=None, shift=None):

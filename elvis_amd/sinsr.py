@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from .ops import Act, PackedConv
+from .ops import Act, PackedConv, PackedUpConv
 from .weights import SinSRConfig, frame_noise, make_sinsr_weights, timestep_embedding, unet_layout
 
 
@@ -29,6 +29,20 @@ class _GN:
 
 def _conv(sd, p, dtype, device, cin, cin2=0) -> PackedConv:
     return PackedConv(sd[p + ".weight"], sd[p + ".bias"], dtype, device, cin, cin2)
+
+
+class _UpConv:
+    """nearest-2x upsample + 3x3 conv: sub-pixel 2x2 decomposition (2.25x fewer FLOPs) or the
+    fused-upsample 3x3 kernel (ELVIS_NO_SUBPIXEL=1 / subpixel=False), same results to rounding."""
+
+    def __init__(self, sd, p, dtype, device, cin, subpixel=True):
+        self.sub = PackedUpConv(sd[p + ".weight"], sd[p + ".bias"], dtype, device, cin) if subpixel else None
+        self.full = None if subpixel else _conv(sd, p, dtype, device, cin)
+
+    def __call__(self, x: Act, want_stats=False) -> Act:
+        if self.sub is not None:
+            return self.sub(x, want_stats=want_stats)
+        return self.full(x, upsample=True, want_stats=want_stats)
 
 
 def _linear(sd, p, dtype, device) -> PackedConv:
@@ -124,6 +138,8 @@ class SinSRModel:
     def __init__(self, cfg: SinSRConfig = SinSRConfig(), state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = True):
         self.cfg, self.device, self.dtype, self.fuse_gn = cfg, torch.device(device), dtype, fuse_gn
+        import os
+        self.subpixel_up = not os.environ.get("ELVIS_NO_SUBPIXEL")
         sd = state_dict if state_dict is not None else make_sinsr_weights(cfg, weight_seed)
         dev = self.device
         with torch.cuda.device(dev):
@@ -160,7 +176,9 @@ class SinSRModel:
                                  scale=ss[:cout].contiguous(), shift=ss[cout:].contiguous())
             if kind == "swin":
                 return _SwinLayer(sd, p, meta[0], cfg, dt, dev)
-            if kind in ("down", "up"):
+            if kind == "up":
+                return _UpConv(sd, p, dt, dev, meta[0], self.subpixel_up)
+            if kind == "down":
                 return _conv(sd, p, dt, dev, meta[0])
             raise ValueError(kind)
 
@@ -213,7 +231,7 @@ class SinSRModel:
             for b in range(nrb + 1):
                 blocks.append(rb(f"ae.decoder.up.{lvl}.block.{b}", cin, ch * mults[lvl]))
                 cin = ch * mults[lvl]
-            us = _conv(sd, f"ae.decoder.up.{lvl}.upsample.conv", dt, dev, cin) if lvl != 0 else None
+            us = _UpConv(sd, f"ae.decoder.up.{lvl}.upsample.conv", dt, dev, cin, self.subpixel_up) if lvl != 0 else None
             self.d_up.append((blocks, us))
         self.d_norm_out = _GN(sd, "ae.decoder.norm_out", dev)
         self.d_conv_out = _conv(sd, "ae.decoder.conv_out", dt, dev, cin)
@@ -236,7 +254,7 @@ class SinSRModel:
                 elif kind == "down":
                     h = m(h, stride=2)
                 elif kind == "up":
-                    h = m(h, upsample=True, want_stats=self.fuse_gn)
+                    h = m(h, want_stats=self.fuse_gn)
                 else:
                     h = m(h)
             return h
@@ -274,7 +292,7 @@ class SinSRModel:
             for b in blocks:
                 h = b(h, fuse_gn=self.fuse_gn)
             if us is not None:
-                h = us(h, upsample=True, want_stats=self.fuse_gn)
+                h = us(h, want_stats=self.fuse_gn)
         out = self._gn_silu_conv(h, self.d_norm_out, self.d_conv_out, 1e-6)
         return (out, idx) if want_idx else out
 

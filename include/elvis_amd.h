@@ -121,13 +121,16 @@ typedef struct elvis_conv_desc {
     int cin, cin_pitch; /* channels of input 1 and its pitch                                   */
     int cin2, cin2_pitch; /* optional second input (virtual channel concat), 0 if unused       */
     int cout, cout_pitch; /* logical output channels, output pitch                             */
-    int ksize;          /* 1 or 3                                                              */
+    int ksize;          /* 1 or 3 (2: one parity of a sub-pixel upsample conv, see `subpixel`)  */
     int stride;         /* 1 or 2                                                              */
     int pad_before;     /* zero padding before (top/left); after is implied by ho/wo           */
     int upsample;       /* 1: input is nearest-upsampled 2x before the conv                    */
     int ho, wo;         /* output spatial size                                                 */
     int act;            /* epilogue activation: 0 none, 1 GELU(erf), 2 SiLU                    */
     int prologue;       /* 0 none, 1: x <- silu(x*pa[n,c]+pb[n,c]) on load (fused GroupNorm)   */
+    int subpixel;       /* ksize == 2 only: 1 + parity (2a+b) of the sub-pixel decomposition of
+                           "nearest-2x upsample + 3x3 conv": this launch writes output pixels
+                           (2y+a, 2x+b) of the 2h x 2w output from 2x2 pre-summed taps          */
 } elvis_conv_desc;
 
 /* Number of bytes of the packed weight buffer for a conv (depends on cin/cin2/cout/ksize/dtype). */

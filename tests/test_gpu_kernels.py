@@ -195,6 +195,32 @@ def test_conv_1x1_tiled(gpu_device, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [(128, 128, 20, 37), (64, 192, 16, 32), (320, 320, 9, 40), (512, 512, 33, 35)])
+def test_subpixel_upsample_conv(gpu_device, dtype, cfg):
+    """nearest-2x + 3x3 conv as four 2x2 sub-pixel convs == the direct formulation."""
+    from elvis_amd import ops
+    cin, cout, h, w = cfg
+    g = torch.Generator().manual_seed(14)
+    n = 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    up = ops.PackedUpConv(wt, b, dtype, gpu_device, cin)
+    xa = _act(x, dtype, gpu_device)
+    y = up(xa, want_stats=True)
+    ref = F.conv2d(F.interpolate(x.to(dtype).float(), scale_factor=2, mode="nearest"), wt.to(dtype).float(), b, padding=1)
+    got = _nchw(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL[dtype] * 1.5
+    sums = torch.zeros((n, cout, 2), dtype=torch.float64, device=gpu_device)
+    from elvis_amd._lib import lib, check, ptr
+    check(lib().elvis_gn_partials_to_sums(ptr(y.stats), y.stats.shape[0] // n, n, cout, ptr(sums), cout, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+    assert torch.allclose(sums.cpu()[:, :, 0], got.double().sum((2, 3)), rtol=1e-5, atol=2e-2)
+    assert torch.allclose(sums.cpu()[:, :, 1], (got.double() ** 2).sum((2, 3)), rtol=1e-5, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("c,groups", [(64, 32), (160, 32), (96, 8)])
 def test_groupnorm_silu(gpu_device, dtype, c, groups):
     from elvis_amd import ops
