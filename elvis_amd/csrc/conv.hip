@@ -524,15 +524,30 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
                 if (!pix_ok || co >= p.cout) continue;
                 const int nv = p.cout - co < 4 ? p.cout - co : 4;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = 0.f;
-                    if (r < nv) {
-                        if (p.bias) v = p.bias[co + r];
-                        if (p.res) v += to_f(((const T*)p.res)[m * p.res_pitch + co + r]);
-                    }
-                    acc[i][j][r] = v;
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nv) v[r] = p.bias[co + r];
                 }
+                if (p.res) {
+                    const T* rp = (const T*)p.res + m * p.res_pitch + co;
+                    if (nv == 4) {   // one 8-byte (f16) / 16-byte (f32) load per sub-tile
+                        if constexpr (sizeof(T) == 2) {
+                            half4 rv = *reinterpret_cast<const half4*>(rp);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                        } else {
+                            float4v rv = *reinterpret_cast<const float4v*>(rp);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                        }
+                    } else {
+                        for (int r = 0; r < nv; ++r) v[r] += to_f(rp[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = v[r];
             }
         }
     }
