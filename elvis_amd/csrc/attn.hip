@@ -1,8 +1,10 @@
-// Swin (shifted-)window attention on an NHWC token image.  One workgroup per (window, head):
-// 64 tokens x head_dim 32.  QK^T + relative-position bias + shift mask -> softmax -> PV, all in
-// fp32 on LDS-resident tiles; the cyclic shift / window partition / reverse are pure index math
+// Swin (shifted-)window attention on an NHWC token image: 64 tokens x head_dim 32 per (window,
+// head).  QK^T + relative-position bias + shift mask -> softmax -> PV.  f16 tensors run on the
+// matrix cores (window_attention_mfma_kernel below); the exact-parity f32 mode runs in fp32 VALU on
+// LDS-resident tiles; the cyclic shift / window partition / reverse are pure index math
 // (tokens never leave image order in HBM).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -100,6 +102,157 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const T* __restri
     for (int d = 0; d < 8; ++d) dst[d] = from_f<T>(o[d]);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// MFMA form (f16 tensors): one wave per (window, head).
+//   S[i][j] = sum_d Q[i][d] K[j][d]      16 x v_mfma_f32_16x16x32_f16, Q/K fragments straight from
+//                                        global memory (a token's 32-d head slice is 64 contiguous bytes)
+//   P = softmax_j(S*scale + bias + mask) in registers: a row lives in 4 registers x 16 lanes,
+//                                        reduced with DPP/shuffle xor 1,2,4,8
+//   O[i][d] = sum_j P[i][j] V[j][d]      16 MFMAs; P goes through a per-wave LDS tile to become an A
+//                                        operand (row = token, k = key contiguous), V through a
+//                                        padded LDS tile read transposed (k = key, col = d)
+constexpr int P_PITCH = NTOK + 8;   // halfs; 144-byte rows keep ds_read_b128 16-byte aligned
+constexpr int V_PITCH = HD + 1;     // halfs; odd pitch spreads the transposed 2-byte reads over banks
+
+__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t* __restrict__ qkv,
+                                                                    half_t* __restrict__ out, int h, int w,
+                                                                    int heads, int shift, int qkv_pitch,
+                                                                    int out_pitch,
+                                                                    const float* __restrict__ bias_table,
+                                                                    float scale) {
+    __shared__ __attribute__((aligned(16))) half_t sP[4][NTOK * P_PITCH];
+    __shared__ half_t sV[4][NTOK * V_PITCH];
+    __shared__ float sBias[4][(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int s_pos[NTOK];
+    __shared__ int s_region[NTOK];
+    const int E = heads * HD;
+    const int nwx = w / WS, nwy = h / WS;
+    int bid = blockIdx.x;
+    const int wx = bid % nwx;
+    bid /= nwx;
+    const int wy = bid % nwy;
+    const int n = bid / nwy;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid < NTOK) {
+        int ty = tid / WS, tx = tid % WS;
+        int yr = wy * WS + ty, xr = wx * WS + tx;
+        int y = yr + shift, x = xr + shift;
+        if (y >= h) y -= h;
+        if (x >= w) x -= w;
+        s_pos[tid] = (n * h + y) * w + x;
+        int rh = 0, rw = 0;
+        if (shift) {
+            rh = yr < h - WS ? 0 : (yr < h - shift ? 1 : 2);
+            rw = xr < w - WS ? 0 : (xr < w - shift ? 1 : 2);
+        }
+        s_region[tid] = rh * 3 + rw;
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, lq = lane >> 4;
+    half_t* myP = sP[wave];
+    half_t* myV = sV[wave];
+    float* myB = sBias[wave];
+
+    for (int head = wave; head < heads; head += 4) {
+        // relative-position bias column of this head -> LDS
+        for (int t = lane; t < (2 * WS - 1) * (2 * WS - 1); t += 64) myB[t] = bias_table[t * heads + head];
+        // V tile (64 keys x 32 dims) -> LDS, one 16-byte chunk per lane-iteration
+        for (int t = lane; t < NTOK * 4; t += 64) {
+            int j = t >> 2, c = t & 3;
+            half8 v8 = *reinterpret_cast<const half8*>(qkv + (long long)s_pos[j] * qkv_pitch + 2 * E + head * HD + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) myV[j * V_PITCH + c * 8 + e] = v8[e];
+        }
+        // Q (A operand) and K (B operand) fragments straight from global memory
+        half8 fq[4], fk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int tok = t * 16 + lr;
+            fq[t] = *reinterpret_cast<const half8*>(qkv + (long long)s_pos[tok] * qkv_pitch + head * HD + lq * 8);
+            fk[t] = *reinterpret_cast<const half8*>(qkv + (long long)s_pos[tok] * qkv_pitch + E + head * HD + lq * 8);
+        }
+        float4v sacc[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                sacc[it][jt] = (float4v){0.f, 0.f, 0.f, 0.f};
+                sacc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fq[it], fk[jt], sacc[it][jt], 0, 0, 0);
+            }
+        // softmax over j for each row i = it*16 + lq*4 + r ; this lane holds columns j = jt*16 + lr
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + lq * 4 + r;
+                const int yi = i / WS, xi = i % WS;
+                const int reg_i = s_region[i];
+                float v[4];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const int j = jt * 16 + lr;
+                    const int yj = j / WS, xj = j % WS;
+                    float a = sacc[it][jt][r] * scale + myB[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)];
+                    if (shift && s_region[j] != reg_i) a += -100.0f;
+                    v[jt] = a;
+                    mx = fmaxf(mx, a);
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    v[jt] = __expf(v[jt] - mx);
+                    sum += v[jt];
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) myP[i * P_PITCH + jt * 16 + lr] = (half_t)(v[jt] * inv);
+            }
+        // (wave-local LDS tile: no workgroup barrier needed, only the LDS writes to land)
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        // O = P V : A = P[i][j] (rows on lr, k contiguous), B[k=j][col=d] from the V tile
+        float4v oacc[4][2];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oacc[it][dt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 fv[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fv[dt][e] = myV[(ks * 32 + lq * 8 + e) * V_PITCH + dt * 16 + lr];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                half8 fp = *reinterpret_cast<const half8*>(myP + (it * 16 + lr) * P_PITCH + ks * 32 + lq * 8);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    oacc[it][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fp, fv[dt], oacc[it][dt], 0, 0, 0);
+            }
+        }
+        // store: lane holds O[i = it*16 + lq*4 + r][d = dt*16 + lr]
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + lq * 4 + r;
+                half_t* dst = out + (long long)s_pos[i] * out_pitch + head * HD;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dst[dt * 16 + lr] = (half_t)oacc[it][dt][r];
+            }
+        __builtin_amdgcn_wave_barrier();   // the next head reuses this wave's LDS tiles
+    }
+}
+
 }  // namespace
 
 extern "C" int elvis_window_attention(const void* qkv, void* out, int dtype, int n, int h, int w, int heads,
@@ -112,7 +265,12 @@ extern "C" int elvis_window_attention(const void* qkv, void* out, int dtype, int
     ELVIS_REQUIRE(qkv_pitch >= 3 * heads * head_dim && out_pitch >= heads * head_dim, "elvis_window_attention: bad pitch");
     long long blocks = (long long)n * (h / ws) * (w / ws) * heads;
     ELVIS_REQUIRE(blocks < 0x7fffffffLL, "elvis_window_attention: grid too large");
-    if (dtype == ELVIS_F16)
+    if (dtype == ELVIS_F16 && !getenv("ELVIS_ATTN_VALU")) {
+        // MFMA path: one workgroup per window, waves loop over heads
+        long long wblocks = (long long)n * (h / ws) * (w / ws);
+        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)wblocks), dim3(256), 0, (hipStream_t)stream,
+                           (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);
+    } else if (dtype == ELVIS_F16)
         hipLaunchKernelGGL(window_attention_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);
     else if (dtype == ELVIS_F32)
