@@ -11,7 +11,8 @@ from .sharding import (ChunkSpec, chunk_for_devices, parallel_process_frames, ra
 from .recompose import (combine_blocks_into_image, split_image_into_blocks,  # noqa: F401
                         restore_video_adaptively)
 from .tiler import adaptive_restore, blended_restoration, resource_aware_restore  # noqa: F401
-from .restore import (get_sinsr_model, get_sinsr_upsample_fn, restore_frames_rounds,  # noqa: F401
-                      restore_frames_sinsr, restore_with_sinsr_naive)
+from .restore import (get_sinsr_model, get_sinsr_upsample_fn, restore_frames_blur,  # noqa: F401
+                      restore_frames_dct, restore_frames_rounds, restore_frames_sinsr,
+                      restore_with_sinsr_naive)
 
 __version__ = "0.1.0"

@@ -283,6 +283,9 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
             } else if (p.act == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            } else if (p.act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
             }
             if (p.res) {
                 const T* rp = (const T*)p.res + m * p.res_pitch + co;
@@ -716,6 +719,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             } else if (p.act == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            } else if (p.act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
             }
             if (p.res && !fold) {
                 const T* rp = (const T*)p.res + m * p.res_pitch + co;

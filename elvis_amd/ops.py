@@ -276,7 +276,7 @@ class PackedUpConv:
                         w2[:, :, dyi, dxi] = sum(w[:, :, r, c] for r in rows for c in cols)
                 self.par.append(PackedConv(w2, bias, dtype, device, cin))
 
-    def __call__(self, x: Act, want_stats: bool = False) -> Act:
+    def __call__(self, x: Act, want_stats: bool = False, act: int = 0) -> Act:
         n, h, w = x.n, x.h, x.w
         out = new_act(n, 2 * h, 2 * w, self.cout, x.t.dtype, x.t.device)
         stats = None
@@ -285,7 +285,7 @@ class PackedUpConv:
             d.dtype = x.dtype_code
             d.n, d.h, d.w = n, h, w
             d.cin, d.cin_pitch = x.c, x.pitch
-            d.ksize, d.stride, d.subpixel = 2, 1, 1 + k
+            d.ksize, d.stride, d.subpixel, d.act = 2, 1, 1 + k, act
             d.ho, d.wo = 2 * h, 2 * w
             d.cout, d.cout_pitch = self.cout, out.pitch
             tiles = lib().elvis_conv_stats_tiles(C.byref(d))
@@ -386,4 +386,35 @@ def crop_copy(x: Act, h, w) -> Act:
     out = new_act(x.n, h, w, x.c, x.t.dtype, x.t.device, zero=False)
     check(lib().elvis_crop_copy(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.pitch, h, w, x.c, out.pitch,
                                 _s(x.t)), x.t.device)
+    return out
+
+
+# ----------------------------------------------------------------------------- DCT-slot kernels
+def dcnv2(x: Act, om: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], groups: int, cout: int,
+          mask_sigmoid: bool = True, act: int = 0) -> Act:
+    """Modulated deformable 3x3 conv.  om: offsets (18*G) then masks (9*G) channels; weight
+    [cout, cin, 3, 3] tensor already in the activation dtype on the device."""
+    out = new_act(x.n, x.h, x.w, cout, x.t.dtype, x.t.device)
+    check(lib().elvis_dcnv2(ptr(x.t), ptr(om.t), ptr(weight), ptr(bias), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c,
+                            x.pitch, groups, om.pitch, int(mask_sigmoid), cout, out.pitch, act, _s(x.t)), x.t.device)
+    return out
+
+
+def temporal_stack(frames_u8: torch.Tensor, f0: int, nsel: int, radius: int, dtype) -> Act:
+    """[F,H,W,3] u8 -> Act [(nsel*3), H, W, pitch]: the 2R+1 temporal window of every colour plane."""
+    _chk_u8(frames_u8)
+    nf, h, w, _ = frames_u8.shape
+    t = 2 * radius + 1
+    out = torch.empty((nsel * 3, h, w, pitch_for(t)), dtype=dtype, device=frames_u8.device)
+    check(lib().elvis_temporal_stack(ptr(frames_u8), ptr(out), L.dtype_code(dtype), nf, f0, nsel, h, w, radius,
+                                     out.shape[3], _s(out)), frames_u8.device)
+    return Act(out, t)
+
+
+def plane_merge(frames_u8: torch.Tensor, residual: Act, f0: int, nsel: int) -> torch.Tensor:
+    _chk_u8(frames_u8)
+    _, h, w, _ = frames_u8.shape
+    out = torch.empty((nsel, h, w, 3), dtype=torch.uint8, device=frames_u8.device)
+    check(lib().elvis_plane_merge(ptr(frames_u8), ptr(residual.t), ptr(out), residual.dtype_code, f0, nsel, h, w,
+                                  residual.pitch, _s(out)), frames_u8.device)
     return out

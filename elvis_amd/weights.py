@@ -254,3 +254,86 @@ def frame_noise(cfg: SinSRConfig, seed: int, frame_index: int, hp: int, wp: int)
     input tensor (SURVEY.md 7.2 "Stochastic sampler")."""
     g = torch.Generator().manual_seed(int(seed) * 1000003 + int(frame_index))
     return torch.randn(1, cfg.latent_ch, hp, wp, generator=g, dtype=torch.float32)
+
+
+# =========================================================================================
+# The other two model slots of ELVIS v2 (SURVEY.md 8a rows a7 / a8).  Neither model has source,
+# weights or tests in the reference (README.md:11-25 only names them), so - like SinSR above - the
+# architectures are the build's documented choice and the weights are seeded synthetic.
+
+@dataclass(frozen=True)
+class DCNRestorerConfig:
+    """LaplacianVCAR slot (ELVIS v2 DCT): STDF-style spatio-temporal deformable restorer.
+    T = 2*radius+1 planes -> small U-Net -> 9 offsets (+ mask) per plane -> DCNv2(T -> feat, 3x3,
+    deformable_groups = T) -> plain 3x3 CNN -> residual on the centre plane."""
+    radius: int = 3
+    off_ch: int = 32
+    feat: int = 64
+    qe_layers: int = 3
+
+    @property
+    def t(self) -> int:
+        return 2 * self.radius + 1
+
+
+@dataclass(frozen=True)
+class SwinDeblurConfig:
+    """SwinTormer slot (ELVIS v2 Blur): Restormer-like U-shape whose transformer blocks use Swin
+    (shifted-)window attention (window 8, head_dim 32) and a GELU MLP."""
+    ch: int = 64
+    blocks: Tuple[int, ...] = (2, 2, 2)     # encoder level 1, level 2, bottleneck (decoder mirrors 2,1)
+    mlp_ratio: int = 2
+    window_size: int = 8
+    head_dim: int = 32
+
+    @property
+    def align(self) -> int:
+        return self.window_size * 4
+
+
+def make_dcn_weights(cfg: DCNRestorerConfig = DCNRestorerConfig(), seed: int = 0) -> Dict[str, torch.Tensor]:
+    I = _Init(seed + 101)
+    t, oc, f = cfg.t, cfg.off_ch, cfg.feat
+    I.conv("off.c1", t, oc, 3)
+    I.conv("off.d1", oc, oc, 3)
+    I.conv("off.d2", oc, oc, 3)
+    I.conv("off.u1", oc, oc, 3)
+    I.conv("off.f", 2 * oc, oc, 3)
+    I.conv("off.om", oc, 27 * t, 3, gain=0.5)
+    I.conv("dcn", t, f, 3)
+    for i in range(cfg.qe_layers):
+        I.conv(f"qe.{i}", f, f, 3)
+    I.conv("qe.out", f, 1, 3, gain=0.3)
+    return I.sd
+
+
+def make_deblur_weights(cfg: SwinDeblurConfig = SwinDeblurConfig(), seed: int = 0) -> Dict[str, torch.Tensor]:
+    I = _Init(seed + 202)
+    C, ws = cfg.ch, cfg.window_size
+
+    def blocks(prefix, ch, n):
+        heads = ch // cfg.head_dim
+        for i in range(n):
+            b = f"{prefix}.{i}"
+            I.norm(b + ".norm1", ch)
+            I.sd[b + ".attn.relative_position_bias_table"] = I.randn((2 * ws - 1) ** 2, heads, std=0.2)
+            I.linear(b + ".attn.qkv", ch, 3 * ch)
+            I.linear(b + ".attn.proj", ch, ch, gain=0.5)
+            I.norm(b + ".norm2", ch)
+            I.linear(b + ".mlp.fc1", ch, cfg.mlp_ratio * ch)
+            I.linear(b + ".mlp.fc2", cfg.mlp_ratio * ch, ch, gain=0.5)
+
+    I.conv("embed", 3, C, 3)
+    blocks("enc1", C, cfg.blocks[0])
+    I.conv("down1", C, 2 * C, 3)
+    blocks("enc2", 2 * C, cfg.blocks[1])
+    I.conv("down2", 2 * C, 4 * C, 3)
+    blocks("mid", 4 * C, cfg.blocks[2])
+    I.conv("up2", 4 * C, 2 * C, 3)
+    I.conv("red2", 4 * C, 2 * C, 1)
+    blocks("dec2", 2 * C, cfg.blocks[1])
+    I.conv("up1", 2 * C, C, 3)
+    I.conv("red1", 2 * C, C, 1)
+    blocks("dec1", C, cfg.blocks[0])
+    I.conv("out", C, 3, 3, gain=0.3)
+    return I.sd

@@ -126,7 +126,7 @@ typedef struct elvis_conv_desc {
     int pad_before;     /* zero padding before (top/left); after is implied by ho/wo           */
     int upsample;       /* 1: input is nearest-upsampled 2x before the conv                    */
     int ho, wo;         /* output spatial size                                                 */
-    int act;            /* epilogue activation: 0 none, 1 GELU(erf), 2 SiLU                    */
+    int act;            /* epilogue activation: 0 none, 1 GELU(erf), 2 SiLU, 3 ReLU            */
     int prologue;       /* 0 none, 1: x <- silu(x*pa[n,c]+pb[n,c]) on load (fused GroupNorm)   */
     int subpixel;       /* ksize == 2 only: 1 + parity (2a+b) of the sub-pixel decomposition of
                            "nearest-2x upsample + 3x3 conv": this launch writes output pixels
@@ -208,6 +208,26 @@ int elvis_pad_reflect_axpy(const void* x, void* y, int dtype, int n, int h, int 
 /* y[n,h,w,:c] = x[n,:h,:w,:c] crop-copy between pitched tensors (dtype-preserving). */
 int elvis_crop_copy(const void* x, void* y, int dtype, int n, int h_in, int w_in, int pitch_in, int h,
                     int w, int c, int pitch_out, elvis_stream_t stream);
+
+/* ------------------------------------------------------------------ DCT slot (LaplacianVCAR-style) */
+
+/* DCNv2 modulated deformable 3x3 convolution (stride 1, pad 1, dilation 1), NHWC.
+ * offset_mask[n,h,w,om_pitch]: channels [0, 18*G) offsets ((g*9+k)*2 + {dy,dx}), [18*G, 27*G) masks
+ * (g*9+k); `mask_sigmoid` applies the sigmoid to the mask channels on load.  weight: [cout][cin][9]
+ * in the tensor dtype, bias f32[cout] or NULL, act 0 / 3 (ReLU).  Out-of-image bilinear corners
+ * contribute zero.  The reference only names this op (README.md:14-16, an absent CUDA build). */
+int elvis_dcnv2(const void* x, const void* offset_mask, const void* weight, const float* bias, void* out,
+                int dtype, int n, int h, int w, int cin, int x_pitch, int deformable_groups, int om_pitch,
+                int mask_sigmoid, int cout, int out_pitch, int act, elvis_stream_t stream);
+
+/* frames u8 [nf,h,w,3] -> planes [(f*3+c), h, w, pitch] for f in [f0, f0+nsel): channel t holds
+ * colour c of frame clamp(f + t - radius) / 255 (the temporal window of the DCN restorer). */
+int elvis_temporal_stack(const uint8_t* frames, void* out, int dtype, int nf, int f0, int nsel, int h, int w,
+                         int radius, int pitch, elvis_stream_t stream);
+
+/* out_u8[f,h,w,c] = round(clip(frames[f0+f][c]/255 + residual[(f*3+c),h,w,0], 0, 1) * 255). */
+int elvis_plane_merge(const uint8_t* frames, const void* residual, uint8_t* out, int dtype, int f0, int nsel,
+                      int h, int w, int pitch, elvis_stream_t stream);
 
 #ifdef __cplusplus
 }
