@@ -818,9 +818,13 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
 }
 // 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
 // (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
-constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TX = 32;
+constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TY_PRO128 = 12, HALO_TX = 32;
 // 1x1 convs are HBM/latency-bound: the 8-row tile halves LDS and registers so two workgroups fit a CU
-inline int halo_ty(int prologue, int ksize = 3) { return (prologue || ksize == 1) ? HALO_TY_PRO : HALO_TY; }
+// the fused-prologue kernel with a 128-channel tile uses 12 rows (64co x 96px per wave, ~210 VGPRs)
+inline int halo_ty(int prologue, int ksize, int tco) {
+    if (ksize == 3 && prologue && tco == 128) return HALO_TY_PRO128;
+    return (prologue || ksize == 1) ? HALO_TY_PRO : HALO_TY;
+}
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
 
 int validate(const elvis_conv_desc* d) {
@@ -863,7 +867,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 512;
-    constexpr int TY = (PRO || KS == 1) ? HALO_TY_PRO : HALO_TY;
+    constexpr int TY = (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
     const size_t lds_fixed = 2 * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + (KS == 2 ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
@@ -959,7 +963,7 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
 
 extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     if (!d || !halo_eligible(d)) return 0;
-    int ty = halo_ty(d->prologue, d->ksize);
+    int ty = halo_ty(d->prologue, d->ksize, choose_tile(d->cout).tco);
     if (d->ksize == 2) return d->n * ((d->h + ty - 1) / ty) * ((d->w + HALO_TX - 1) / HALO_TX);   // per parity launch
     return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
 }
@@ -992,7 +996,8 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.par_a = d->ksize == 2 ? (d->subpixel - 1) >> 1 : 0;
     a.par_b = d->ksize == 2 ? (d->subpixel - 1) & 1 : 0;
     a.tiles_x = ((d->ksize == 2 ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
-    a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + halo_ty(d->prologue, d->ksize) - 1) / halo_ty(d->prologue, d->ksize);
+    const int tyv = halo_ty(d->prologue, d->ksize, t.tco);
+    a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + tyv - 1) / tyv;
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
         hipStream_t st = (hipStream_t)stream;

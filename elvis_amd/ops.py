@@ -241,7 +241,8 @@ def conv_kernel_name(cout: int, dtype_code: int, halo: bool, prologue: bool = Fa
     if halo:
         tco = 128 if cout % 128 == 0 else (64 if cout >= 64 else (16 if cout <= 16 else 32))
         return (f"conv3x3_halo_kernel<{t},{tco},512,"
-                f"{8 if (prologue or ksize == 1) else 16},{'true' if prologue else 'false'},{ksize}>")
+                f"{12 if (prologue and ksize == 3 and tco == 128) else (8 if (prologue or ksize == 1) else 16)},"
+                f"{'true' if prologue else 'false'},{ksize}>")
     if cout % 128 == 0:
         return f"conv_igemm_kernel<{t},4,4,2,2>"
     if cout >= 64:

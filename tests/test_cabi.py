@@ -51,4 +51,4 @@ def test_argument_validation_without_gpu():
     d.ksize, d.pad_before, d.h, d.w, d.ho, d.wo, d.n = 3, 1, 1080, 1920, 1080, 1920, 1
     assert h.elvis_conv_stats_tiles(C.byref(d)) == 68 * 60      # 16 x 32 pixel tiles
     d.prologue = 1
-    assert h.elvis_conv_stats_tiles(C.byref(d)) == 135 * 60     # 8 x 32 tiles with the fused prologue
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 90 * 60      # 12 x 32 tiles with the fused prologue (128-ch tile)
