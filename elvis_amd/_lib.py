@@ -13,7 +13,8 @@ import threading
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(HERE, "lib", "libelvis_amd.so")
+# ELVIS_AMD_LIB: alternative build of the same library (kernel A/B experiments, tools/build_variant.py)
+LIBPATH = os.environ.get("ELVIS_AMD_LIB") or os.path.join(HERE, "lib", "libelvis_amd.so")
 
 F32, F16 = 0, 1
 ROUND_CV2, ROUND_HALF_UP = 0, 1
@@ -47,6 +48,7 @@ SIGNATURES = {
     "elvis_conv_pack_weights": [C.POINTER(ConvDesc), vp, vp, vp],
     "elvis_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp],
     "elvis_conv_stats_tiles": [C.POINTER(ConvDesc)],
+    "elvis_conv_kernel_name": [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t],
     "elvis_gn_partials_to_sums": [vp, i32, i32, i32, vp, i32, i32, vp],
     "elvis_groupnorm_workspace_floats": [i32, i32, i32, i32],
     "elvis_groupnorm_sums": [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp],

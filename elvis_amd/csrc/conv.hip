@@ -43,6 +43,7 @@ struct ConvArgs {
     int n_co_tiles;
     long long n_px_tiles;
     // halo kernel only
+    int two;              // 256-thread two-workgroups-per-CU variant
     float* stats;         // [n*tiles_y*tiles_x][cout][2] partial (sum, sumsq) or null
     int tiles_x, tiles_y;
     int sub, par_a, par_b;   // sub-pixel mode (KS == 2): output pixel (2y+par_a, 2x+par_b)
@@ -68,6 +69,18 @@ __device__ __forceinline__ int lds_row_off(int row, int q) {
     // against the gfx950 lane-group table), which the halo kernel needs for its dx-shifted reads.
     return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4);
 }
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15); every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <typename T> struct PrologueVec { float a[DT<T>::VEC], b[DT<T>::VEC]; };
 template <typename T> __device__ __forceinline__ uint4 prologue_apply(uint4 v, const float (&pa)[DT<T>::VEC], const float (&pb)[DT<T>::VEC]);
@@ -320,8 +333,11 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
 // Epilogue: bias / activation / residual, NHWC store, and per-tile GroupNorm partial sums
 // (sum, sum of squares per output channel) for the NEXT layer's normalisation - no atomics, the
 // partials are reduced by elvis_gn_partials_to_sums.
-template <typename T, int TCO, int NT, int TY, bool PRO, int KS = 3>
-__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
+// ACT = false: no epilogue activation compiled in (act == 0: bias/residual folded into the
+// accumulator start).  The activation code (erf GELU, SiLU with a precise division) is large; keeping
+// it out of the hot instantiations keeps prologue + loop + epilogue inside the instruction cache.
+template <typename T, int TCO, int NT, int TY, bool PRO, int KS = 3, bool ACT = false>
+__global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // KS = 3: 3x3 / pad 1 (halo of one pixel).  KS = 1: 1x1 conv / linear layer - the same staging
     // pipeline with no halo and one tap per K chunk (HBM-bound: what matters is bytes in flight).
     // KS = 2: one parity of the sub-pixel decomposition of "nearest-2x upsample + 3x3 conv": the 3x3
@@ -329,7 +345,14 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     // grid for each output parity (a,b), 16 instead of 36 taps per low-res pixel (2.25x fewer FLOPs);
     // top/left padding is 1-a / 1-b and the tile writes output pixels (2y+a, 2x+b).
     constexpr int TX = 32, HX = TX + KS - 1, HY = TY + KS - 1, HP = HX * HY;
-    constexpr int NSLOT = KS == 2 ? 2 : 3;   // weight ring slots; row step r uses slot r % NSLOT (static)
+    // NT = 256 ("TWO"): 4-wave workgroups sized so that TWO of them share a CU (<= 80 KB of LDS, <= 256
+    // VGPRs): one workgroup's start-up loads / epilogue stores overlap the other's MFMA loop.  To fit,
+    // the halo is single-buffered (next chunk staged in registers, written between two barriers) and
+    // the weight ring has two row slots (slot = row step parity).
+    constexpr bool TWO = NT == 256;
+    static_assert(!(TWO && KS == 1), "the 1x1 path keeps the 512-thread layout");
+    constexpr int NSLOT = (TWO || KS == 2) ? 2 : 3;   // weight ring slots; row step r uses slot r % NSLOT
+    constexpr int NHB = TWO ? 1 : 2;                  // halo buffers
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
@@ -347,10 +370,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;                     // 2 buffers of HALO_BYTES
-    char* const wring = smem + 2 * HALO_BYTES;   // NSLOT slots of W_BYTES
+    char* const wring = smem + NHB * HALO_BYTES;   // NSLOT slots of W_BYTES
     // prologue table: per K chunk and 16-byte slice q, VEC x a then VEC x b (f32), so a thread's
     // GroupNorm affine for the slice it stages is two LDS vector reads - no long-lived registers
-    float* const ptab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NSLOT * W_BYTES);
+    float* const ptab = reinterpret_cast<float*>(smem + NHB * HALO_BYTES + NSLOT * W_BYTES);
 
     long long nblk = (long long)p.n_co_tiles * p.tiles_x * p.tiles_y * p.n;
     long long bid = blockIdx.x;
@@ -368,6 +391,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     const int oy0 = ty * TY, ox0 = tx * TX, co0 = co_tile * TCO;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ELVIS_EXP_STAMP   /* diagnostic build: per-workgroup phase cycle counts written over the tile's stats slot */
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+#endif
     const int w_co = wave / NW_PX, w_px = wave % NW_PX;
     const int lh = p.upsample ? p.h * 2 : p.h, lw = p.upsample ? p.w_in * 2 : p.w_in;
 
@@ -495,6 +521,33 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS) *reinterpret_cast<uint4*>(dst + wl_off[i]) = wr[i];
         }
     };
+    // TWO: weights go global -> LDS directly (LDS-DMA, no staging registers).  The DMA writes
+    // lane-linear (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE chunk:
+    // LDS position P = (row P>>2, slot P&3) holds logical chunk q = slot ^ swz(row), whose source
+    // offset is lds_row_off(row, P&3) (the swizzle is an involution) = wl_off[].
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);
+    auto w_glds = [&](int r, int slot) {
+        r = r < nrows ? r : nrows - 1;
+        int kc = r / KS, dy = r - kc * KS;
+        const long long tap_stride = (long long)nkc * p.co_pad * 64;
+        const char* wsrc = (const char*)p.w + ((long long)(dy * KS * nkc + kc) * p.co_pad + co0) * 64;
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i)
+            {
+                // inline asm keeps the DMA out of hipcc's waitcnt bookkeeping (a pending LDS-DMA makes it
+                // emit lgkmcnt(0) for every fragment read); completion = the explicit vmcnt(0) that
+                // precedes each row-step barrier (w_glds_wait)
+                unsigned keep;
+                const unsigned dst = lds_base + (unsigned)((wring - smem) + slot * W_BYTES + t * W_TAP_BYTES + (i * NT + wave_u * 64) * 16);
+                const char* src = wsrc + t * tap_stride + wl_off[i];
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+    };
+    auto w_glds_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto w_store = [&](int slot) {
         char* dst = wring + slot * W_BYTES;
         w_store1(dst, wr0);
@@ -514,8 +567,62 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     // With no epilogue activation, y = conv + bias + residual: start the accumulators from
     // bias + residual so the residual's HBM latency hides under the start-up instead of sitting
     // on the epilogue's critical path.
-    const bool fold = p.act == 0;
-    if (fold && (p.res || p.bias)) {
+    const bool fold = !ACT;   // host guarantees ACT == (act != 0)
+    // vec4: every lane's 4-channel group is whole (cout % 4 == 0) -> branch-free bias / residual /
+    // store code with clamped addresses.  (Per-element branches around loads make hipcc wait
+    // vmcnt(0) per load: 24 serialized round trips per tile, measured 30k cycles.)
+    const bool vec4 = (p.cout & 3) == 0 && (p.res_pitch & 3) == 0;
+    bool co_ok[WCO];
+#pragma unroll
+    for (int i = 0; i < WCO; ++i) co_ok[i] = co0 + (w_co * WCO + i) * 16 + lq * 4 < p.cout;
+    auto load_bias = [&](float (&bv)[WCO][4]) {   // vec4 only: 4 unconditional loads per channel group
+#pragma unroll
+        for (int i = 0; i < WCO; ++i) {
+            const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[i][r] = 0.f;
+            if (p.bias) {
+                const float* bp = p.bias + (co_ok[i] ? co : 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[i][r] = bp[r];
+            }
+        }
+    };
+    if (fold && vec4) {
+        float bv[WCO][4];
+        load_bias(bv);
+        if (p.res) {
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) {
+                const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
+                const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
+                const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+                                            : ((long long)nimg * p.ho + oy) * p.wo + ox;
+                const long long mc = pix_ok ? m : 0;
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) {
+                    const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
+                    const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[i] ? co : 0);
+                    if constexpr (sizeof(T) == 2) {
+                        half4 rv = *reinterpret_cast<const half4*>(rp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = bv[i][r] + (float)rv[r];
+                    } else {
+                        float4v rv = *reinterpret_cast<const float4v*>(rp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = bv[i][r] + rv[r];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = bv[i][r];
+        }
+    } else if (fold && (p.res || p.bias)) {
 #pragma unroll
         for (int j = 0; j < WPX; ++j) {
             const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
@@ -559,7 +666,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
     // The first global loads are issued before the prologue table is built so their latency
     // overlaps it (one workgroup per CU: nothing else hides a workgroup's start-up).
     halo_load(0, 0, H_PER);
-    w_load(0);
+    if constexpr (TWO) w_glds(0, 0); else w_load(0);
     if (PRO) {
         // table entry t = (kc*4 + q)*2*VEC + {0..VEC-1: a, VEC..2VEC-1: b}; channels past the
         // logical count get a = b = 0 (silu(0) = 0 keeps zero padding exact)
@@ -577,10 +684,17 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         __syncthreads();
     }
     halo_store(0, 0, 0, H_PER);
-    w_store(0);
-    w_load(1);
+    if constexpr (TWO) {
+        w_glds_wait();
+    } else {
+        w_store(0);
+        w_load(1);
+    }
     __syncthreads();
 
+#ifdef ELVIS_EXP_STAMP
+    const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
+#endif
     // B-fragment addressing with ZERO per-read VALU.  A lane reads halo pixel x + C (x = its pixel at
     // tap (0,0) of the wave's first sub-tile, C a compile-time pixel offset) at byte
     //   (x+C)*64 + ((lq ^ (swz(x+C) << 1)) << 4),   swz(v) = (v >> 2) & 1.
@@ -609,6 +723,16 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #else
 #define ELVIS_STAGE(x) x
 #endif
+#ifdef ELVIS_EXP_NOW       /* timing experiment only: no weight staging in the loop */
+#define ELVIS_STAGE_W(x)
+#else
+#define ELVIS_STAGE_W(x) ELVIS_STAGE(x)
+#endif
+#ifdef ELVIS_EXP_NOH       /* timing experiment only: no halo staging in the loop */
+#define ELVIS_STAGE_H(x)
+#else
+#define ELVIS_STAGE_H(x) ELVIS_STAGE(x)
+#endif
 #ifdef ELVIS_EXP_NOBARRIER /* timing experiment only */
 #define ELVIS_BARRIER()
 #else
@@ -616,12 +740,50 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #endif
 #define ELVIS_ROW_STEP(DY)                                                                             \
     {                                                                                                  \
-        ELVIS_STAGE(w_store((DY + 1) % NSLOT);)                                                        \
-        ELVIS_STAGE(w_load(r0 + DY + 2);)                                                              \
-        ELVIS_STAGE(if (DY == 0) halo_load(kcn, 0, PRO ? H_PER : HA);)                                 \
-        ELVIS_STAGE(if (DY == 1 && !PRO) halo_load(kcn, HA, H_PER);)                                   \
+        const int rslot = TWO ? ((r0 + DY) & 1) : DY;                                                  \
+        if constexpr (TWO) {                                                                           \
+            ELVIS_STAGE_W(w_glds(r0 + DY + 1, rslot ^ 1);)                                             \
+        } else {                                                                                       \
+            ELVIS_STAGE(w_store((DY + 1) % NSLOT);)                                                    \
+            ELVIS_STAGE(w_load(r0 + DY + 2);)                                                          \
+        }                                                                                              \
+        ELVIS_STAGE_H(if (DY == 0) halo_load(kcn, 0, PRO ? H_PER : HA);)                               \
+        ELVIS_STAGE_H(if (DY == 1 && !PRO) halo_load(kcn, HA, H_PER);)                                 \
+        if constexpr (TWO) {                                                                           \
+            /* software-pipelined fragment reads: the B fragment of step s+1 and the A fragments of   \
+               the next tap are in flight while the MFMAs of step s issue (counted lgkmcnt waits) */  \
+            const char* wsb = wring + rslot * W_BYTES + a_off;                                         \
+            frag_t fa[2][WCO], fb[2];                                                                  \
+            _Pragma("unroll") for (int i = 0; i < WCO; ++i)                                            \
+                fa[0][i] = *reinterpret_cast<const frag_t*>(wsb + i * 1024);                           \
+            {                                                                                          \
+                const int C = DY * HX;                                                                 \
+                fb[0] = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64);     \
+            }                                                                                          \
+            _Pragma("unroll") for (int s = 0; s < KS * WPX; ++s) {                                     \
+                const int dx = s / WPX, j = s - dx * WPX;                                              \
+                if (s + 1 < KS * WPX) {                                                                \
+                    const int ndx = (s + 1) / WPX, nj = (s + 1) - ndx * WPX;                           \
+                    const int C = ((nj >> 1) + DY) * HX + (nj & 1) * 16 + ndx;                         \
+                    fb[(s + 1) & 1] = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64); \
+                }                                                                                      \
+                if (dx + 1 < KS && j < WCO)                                                            \
+                    fa[(dx + 1) & 1][j] = *reinterpret_cast<const frag_t*>(wsb + (dx + 1) * W_TAP_BYTES + j * 1024); \
+                _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[dx & 1][i], fb[s & 1]); \
+                if (PRO && DY >= 1 && j == WPX / 2 - 1) {                                              \
+                    _Pragma("unroll") for (int pi = 0; pi < 2 * H_PER; ++pi)                           \
+                        if (pi * 6 / (2 * H_PER) == (DY - 1) * 3 + dx) { ELVIS_STAGE(halo_act(kcn, pi / 2, pi & 1);) } \
+                }                                                                                      \
+            }                                                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, WCO + 1, 0);                                   \
+            _Pragma("unroll") for (int s = 0; s < KS * WPX; ++s) {                                     \
+                if ((s % WPX) < WCO && s / WPX + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); \
+                else if (s + 1 < KS * WPX) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          \
+                __builtin_amdgcn_sched_group_barrier(0x008, WCO, 0);                                   \
+            }                                                                                          \
+        } else {                                                                                       \
         _Pragma("unroll") for (int dx = 0; dx < KS; ++dx) {                                            \
-            const char* ws = wring + DY * W_BYTES + dx * W_TAP_BYTES + a_off;                          \
+            const char* ws = wring + rslot * W_BYTES + dx * W_TAP_BYTES + a_off;                       \
             frag_t fa[WCO];                                                                            \
             _Pragma("unroll") for (int i = 0; i < WCO; ++i)                                            \
                 fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 1024);                               \
@@ -634,20 +796,22 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                     _Pragma("unroll") for (int pi = 0; pi < 2 * H_PER; ++pi)                           \
                         if (pi * 6 / (2 * H_PER) == (DY - 1) * 3 + dx) {                               \
                             ELVIS_STAGE(halo_act(kcn, pi / 2, pi & 1);)                                \
-                            if (pi & 1) { ELVIS_STAGE(halo_write(kcn, (kc + 1) & 1, pi / 2);) }        \
+                            if ((pi & 1) && !TWO) { ELVIS_STAGE(halo_write(kcn, (kc + 1) & 1, pi / 2);) } \
                         }                                                                              \
                 }                                                                                      \
             }                                                                                          \
             /* interleave the prologue VALU with this tap's MFMAs (1 MFMA : 3 VALU) */                \
-            if (PRO && DY >= 1) {                                                                      \
+            if (PRO && DY >= 1 && !TWO) {                                                              \
                 _Pragma("unroll") for (int g = 0; g < WCO * WPX; ++g) {                                \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                 \
                 }                                                                                      \
             }                                                                                          \
         }                                                                                              \
-        ELVIS_STAGE(if (DY == 0 && !PRO) halo_store(kcn, (kc + 1) & 1, 0, HA);)                        \
-        ELVIS_STAGE(if (DY == 1 && !PRO) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)                    \
+        }                                                                                              \
+        ELVIS_STAGE(if (DY == 0 && !PRO && !TWO) halo_store(kcn, (kc + 1) & 1, 0, HA);)                \
+        ELVIS_STAGE(if (DY == 1 && !PRO && !TWO) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)            \
+        if constexpr (TWO) { ELVIS_STAGE_W(w_glds_wait();) }                                           \
         ELVIS_BARRIER();                                                                               \
     }
     for (int kc = 0; kc < nkc; ++kc) {
@@ -680,14 +844,33 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             halo_store(kcn, (kc + 1) & 1, 0, H_PER);
             __syncthreads();
         }
-        const int delta = (kc & 1) ? -HALO_BYTES : HALO_BYTES;
+        if constexpr (TWO) {
+            // every wave is past its last read of this chunk's halo (barrier of the last row step):
+            // overwrite the single buffer with the register-staged next chunk
+#ifndef ELVIS_EXP_NOH
+            if (kc + 1 < nkc) {
+                if (PRO) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bb[r][0] += delta;
-            bb[r][1] += delta;
+                    for (int i = 0; i < H_PER; ++i) halo_write(kcn, 0, i);
+                } else {
+                    halo_store(kcn, 0, 0, H_PER);
+                }
+            }
+#endif
+            __syncthreads();
+        } else {
+            const int delta = (kc & 1) ? -HALO_BYTES : HALO_BYTES;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bb[r][0] += delta;
+                bb[r][1] += delta;
+            }
         }
     }
 #undef ELVIS_ROW_STEP
+#ifdef ELVIS_EXP_STAMP
+    const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue
     float st[WCO][4], sq[WCO][4];
@@ -696,6 +879,72 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[i][r] = sq[i][r] = 0.f;
     const int cgrp = lq * 4;
+    if (vec4) {
+        // branch-free: clamped addresses, exec-masked stores, no per-element waits
+        float bv[WCO][4];
+        if constexpr (ACT) load_bias(bv);
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+            const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
+            const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
+            const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+                                        : ((long long)nimg * p.ho + oy) * p.wo + ox;
+            const long long mc = pix_ok ? m : 0;
+#pragma unroll
+            for (int i = 0; i < WCO; ++i) {
+                const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+                const bool ok = pix_ok && co_ok[i];
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (ACT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bv[i][r];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                    }
+                    if (p.res) {
+                        const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[i] ? co : 0);
+                        if constexpr (sizeof(T) == 2) {
+                            half4 rv = *reinterpret_cast<const half4*>(rp);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                        } else {
+                            float4v rv = *reinterpret_cast<const float4v*>(rp);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                        }
+                    }
+                }
+                T tv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
+                T* op = (T*)p.out + m * p.cout_pitch + co;
+#ifdef ELVIS_EXP_NOSTORE   /* timing experiment only: stores skipped at run time (never true) */
+                if (p.cout_pitch < 0x7ffffff0) { asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3])); } else
+#endif
+                if (ok) {
+                    if constexpr (sizeof(T) == 2) {
+                        half4 hv = {tv[0], tv[1], tv[2], tv[3]};
+                        *reinterpret_cast<half4*>(op) = hv;
+                    } else {
+                        *reinterpret_cast<float4v*>(op) = (float4v){tv[0], tv[1], tv[2], tv[3]};
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = ok ? to_f(tv[r]) : 0.f;   // statistics of the STORED value
+                    st[i][r] += f;
+                    sq[i][r] = fmaf(f, f, sq[i][r]);
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
@@ -713,15 +962,17 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
                 for (int r = 0; r < 4; ++r)
                     if (r < nv) v[r] += p.bias[co + r];
             }
-            if (p.act == 1) {
+            if constexpr (ACT) {
+                if (p.act == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-            } else if (p.act == 2) {
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                } else if (p.act == 2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
-            } else if (p.act == 3) {
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+                } else if (p.act == 3) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
             }
             if (p.res && !fold) {
                 const T* rp = (const T*)p.res + m * p.res_pitch + co;
@@ -743,6 +994,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             T tv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
+#ifdef ELVIS_EXP_NOSTORE   /* timing experiment only: stores skipped at run time (never true) */
+            if (p.cout_pitch < 0x7ffffff0) { asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3])); } else
+#endif
             if (nv == 4) {
                 if constexpr (sizeof(T) == 2) {
                     half4 hv = {tv[0], tv[1], tv[2], tv[3]};
@@ -770,12 +1024,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
         for (int i = 0; i < WCO; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float a = st[i][r], b = sq[i][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
-                }
+                // the 16 pixel lanes of a channel group are one DPP row: rotate-and-add, no LDS traffic
+                const float a = row16_sum(st[i][r]), b = row16_sum(sq[i][r]);
                 if (lr == 0) {
                     int cl = (w_co * WCO + i) * 16 + cgrp + r;
                     red[(w_px * TCO + cl) * 2 + 0] = a;
@@ -796,6 +1046,21 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(ConvArgs p) {
             dst[1] = b;
         }
     }
+#ifdef ELVIS_EXP_STAMP
+    if (p.stats) {
+        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long stamp4 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (tid == 0) {
+            long long tile = ((long long)nimg * p.tiles_y + ty) * p.tiles_x + tx;
+            float* dst = p.stats + (tile * p.cout + co0) * 2;
+            dst[0] = (float)(stamp1 - stamp0); dst[1] = (float)(stamp2 - stamp1);
+            dst[2] = (float)(stamp3 - stamp2); dst[3] = (float)(stamp4 - stamp3);
+            dst[4] = (float)(stamp0 & 0xffffff); dst[5] = (float)__builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // tile configuration chosen from cout (shared by pack + launch)
@@ -819,13 +1084,24 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
 // 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
 // (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
 constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TY_PRO128 = 12, HALO_TX = 32;
+constexpr int HALO_TY2 = 6;   // 256-thread, two-workgroups-per-CU variant (f16, 128-channel tile, 3x3)
 // 1x1 convs are HBM/latency-bound: the 8-row tile halves LDS and registers so two workgroups fit a CU
 // the fused-prologue kernel with a 128-channel tile uses 12 rows (64co x 96px per wave, ~210 VGPRs)
-inline int halo_ty(int prologue, int ksize, int tco) {
-    if (ksize == 3 && prologue && tco == 128) return HALO_TY_PRO128;
-    return (prologue || ksize == 1) ? HALO_TY_PRO : HALO_TY;
-}
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
+// two-workgroups-per-CU variant: f16, 3x3, 128-channel tile, LDS footprint <= 80 KB
+inline bool halo_two(const elvis_conv_desc* d) {
+    static const int mode = getenv("ELVIS_HALO2") ? atoi(getenv("ELVIS_HALO2")) : 1;   // 0 disables (A/B runs)
+    if (!mode || d->ksize != 3 || d->dtype != ELVIS_F16 || choose_tile(d->cout).tco != 128) return false;
+    if (mode == 2 && !d->prologue) return false;
+    int nkc = (d->cin + 31) / 32 + (d->cin2 > 0 ? (d->cin2 + 31) / 32 : 0);
+    size_t lds = (size_t)(HALO_TY2 + 2) * (HALO_TX + 2) * 64 + 2 * 3 * 128 * 64 + (d->prologue ? (size_t)nkc * 256 : 0);
+    return lds <= 80 * 1024;
+}
+inline int halo_ty(const elvis_conv_desc* d) {
+    if (halo_two(d)) return HALO_TY2;
+    if (d->ksize == 3 && d->prologue && choose_tile(d->cout).tco == 128) return HALO_TY_PRO128;
+    return (d->prologue || d->ksize == 1) ? HALO_TY_PRO : HALO_TY;
+}
 
 int validate(const elvis_conv_desc* d) {
     ELVIS_REQUIRE(d, "conv: null descriptor");
@@ -865,15 +1141,23 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return ELVIS_OK;
 }
 
-template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
-    constexpr int NT = 512;
-    constexpr int TY = (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
-    const size_t lds_fixed = 2 * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + (KS == 2 ? 2 : 3) * KS * (size_t)TCO * 64;
+template <typename T, int TCO, bool PRO, int KS> size_t halo2_lds(int nkc) {
+    return (size_t)((HALO_TY2 + KS - 1) * (HALO_TX + KS - 1) * 64) + 2 * KS * (size_t)TCO * 64 +
+           (PRO ? (size_t)nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
+}
+
+template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
+    if constexpr (!ACT) {
+        if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true>(a, stream);
+    }
+    constexpr bool TWO = NT == 256;
+    constexpr int TY = TWO ? HALO_TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
+    const size_t lds_fixed = (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -883,7 +1167,7 @@ template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArg
     }
     long long nblk = (long long)a.n_co_tiles * a.tiles_x * a.tiles_y * a.n;
     ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_conv2d(halo)");
     return ELVIS_OK;
 }
@@ -891,6 +1175,9 @@ template <typename T, int TCO, bool PRO, int KS> int launch_halo_p(const ConvArg
 template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
     if (a.ksize == 1) return launch_halo_p<T, TCO, false, 1>(a, stream);
     if (a.ksize == 2) return launch_halo_p<T, TCO, false, 2>(a, stream);
+    if constexpr (TCO == 128 && sizeof(T) == 2) {
+        if (a.two) return a.prologue ? launch_halo_p<T, TCO, true, 3, 256>(a, stream) : launch_halo_p<T, TCO, false, 3, 256>(a, stream);
+    }
     return a.prologue ? launch_halo_p<T, TCO, true, 3>(a, stream) : launch_halo_p<T, TCO, false, 3>(a, stream);
 }
 
@@ -963,9 +1250,26 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
 
 extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     if (!d || !halo_eligible(d)) return 0;
-    int ty = halo_ty(d->prologue, d->ksize, choose_tile(d->cout).tco);
+    int ty = halo_ty(d);
     if (d->ksize == 2) return d->n * ((d->h + ty - 1) / ty) * ((d->w + HALO_TX - 1) / HALO_TX);   // per parity launch
     return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
+}
+
+extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_t n) {
+    int rc = validate(d);
+    if (rc) return rc;
+    ELVIS_REQUIRE(buf && n > 0, "elvis_conv_kernel_name: null buffer");
+    const char* t = d->dtype == ELVIS_F16 ? "half" : "float";
+    TileCfg c = choose_tile(d->cout);
+    if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
+        const bool pro = d->ksize == 3 && d->prologue;
+        snprintf(buf, n, "conv3x3_halo_kernel<%s,%d,%d,%d,%s,%d,%s>", t, c.tco, halo_two(d) ? 256 : 512, halo_ty(d),
+                 pro ? "true" : "false", d->ksize, d->act ? "true" : "false");
+    } else {
+        static const int cfg[4][4] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 4, 1, 4}, {1, 4, 1, 4}};
+        snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d>", t, cfg[c.id][0], cfg[c.id][1], cfg[c.id][2], cfg[c.id][3]);
+    }
+    return ELVIS_OK;
 }
 
 extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const void* w_packed,
@@ -996,7 +1300,8 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.par_a = d->ksize == 2 ? (d->subpixel - 1) >> 1 : 0;
     a.par_b = d->ksize == 2 ? (d->subpixel - 1) & 1 : 0;
     a.tiles_x = ((d->ksize == 2 ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
-    const int tyv = halo_ty(d->prologue, d->ksize, t.tco);
+    const int tyv = halo_ty(d);
+    a.two = halo_two(d) ? 1 : 0;
     a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + tyv - 1) / tyv;
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");

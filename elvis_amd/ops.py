@@ -224,32 +224,25 @@ class PackedConv:
         if prof is not None:
             e1.record()
             flops = 2.0 * self.ksize * self.ksize * (self.cin + self.cin2) * self.cout * x.n * ho * wo
-            prof.append((conv_kernel_name(self.cout, x.dtype_code, tiles > 0, prologue is not None, self.ksize), flops, e0, e1))
+            prof.append((conv_kernel_name(d), flops, e0, e1))
+            if CONV_SHAPES is not None:
+                CONV_SHAPES.append((x.n, x.h, x.w, self.cin + self.cin2, self.cout, self.ksize, stride,
+                                    prologue is not None, residual is not None))
         return out
 
 
 # When set to a list, every conv launch appends (kernel_name, algorithmic_flops, start_evt, end_evt);
 # the events are recorded on the stream the kernel is launched on (torch's current stream).
 CONV_PROFILER = None
+CONV_SHAPES = None    # optional parallel list of (n,h,w,cin,cout,ksize,stride,prologue,residual) per launch
 
 
-def conv_kernel_name(cout: int, dtype_code: int, halo: bool, prologue: bool = False, ksize: int = 3) -> str:
-    """Name of the kernel instantiation `elvis_conv2d` dispatches to (conv.hip choose_tile /
-    halo_eligible): conv3x3_halo_kernel<T,TCO,NT,TY,PRO> or conv_igemm_kernel<T,WCO,WPX,NW_CO,NW_PX>
-    - the same template arguments rocprofv3's kernel names carry."""
-    t = "half" if dtype_code == L.F16 else "float"
-    if halo:
-        tco = 128 if cout % 128 == 0 else (64 if cout >= 64 else (16 if cout <= 16 else 32))
-        return (f"conv3x3_halo_kernel<{t},{tco},512,"
-                f"{12 if (prologue and ksize == 3 and tco == 128) else (8 if (prologue or ksize == 1) else 16)},"
-                f"{'true' if prologue else 'false'},{ksize}>")
-    if cout % 128 == 0:
-        return f"conv_igemm_kernel<{t},4,4,2,2>"
-    if cout >= 64:
-        return f"conv_igemm_kernel<{t},2,4,2,2>"
-    if cout <= 16:
-        return f"conv_igemm_kernel<{t},1,4,1,4>"
-    return f"conv_igemm_kernel<{t},2,4,1,4>"
+def conv_kernel_name(d) -> str:
+    """Name of the kernel instantiation `elvis_conv2d` dispatches descriptor `d` to - the template
+    name rocprofv3's kernel trace shows (queried from the library: conv.hip choose_tile / halo_two)."""
+    buf = C.create_string_buffer(128)
+    check(lib().elvis_conv_kernel_name(C.byref(d), buf, len(buf)), None)
+    return buf.value.decode()
 
 
 class PackedUpConv:
@@ -301,8 +294,10 @@ class PackedUpConv:
                                      ptr(sp), _s(x.t)), x.t.device)
             if prof is not None:
                 e1.record()
-                prof.append((conv_kernel_name(self.cout, x.dtype_code, True, False, 2),
+                prof.append((conv_kernel_name(d),
                              2.0 * 4 * self.cin * self.cout * n * h * w, e0, e1))
+                if CONV_SHAPES is not None:
+                    CONV_SHAPES.append((n, h, w, self.cin, self.cout, 2, 1, False, False))
         if stats is not None:
             # per image the reduce expects that image's tiles contiguous: [parity][n*tiles] -> [n][4*tiles/n]
             t_img = tiles // n

@@ -156,6 +156,11 @@ int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void* x2, const 
  * 0 when the conv cannot produce fused statistics. */
 int elvis_conv_stats_tiles(const elvis_conv_desc* d);
 
+/* Writes the name of the kernel instantiation `elvis_conv2d` dispatches this conv to (the template
+ * name rocprofv3's kernel trace shows, e.g. "conv3x3_halo_kernel<half,128,256,6,true,3,false>")
+ * into buf (NUL-terminated, truncated to n).  For per-kernel profiling (bench.py roofline). */
+int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_t n);
+
 /* sums[n, sums_coff + c, 0..1] = sum over the image's tiles of partials[tile][c][0..1] (f64). */
 int elvis_gn_partials_to_sums(const float* partials, int tiles_per_image, int n, int c, double* sums,
                               int sums_ctot, int sums_coff, elvis_stream_t stream);

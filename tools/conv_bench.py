@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--prologue", action="store_true")
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--res", action="store_true", help="add a residual input")
+    ap.add_argument("--n", type=int, default=1, help="batch")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if a.dtype == "f16" else torch.float32
@@ -35,25 +37,32 @@ def main():
             continue
         wt = torch.randn(co, c1 + c2, k, k, generator=g) / math.sqrt((c1 + c2) * k * k)
         conv = ops.PackedConv(wt, torch.randn(co, generator=g), dt, dev, c1, c2)
-        x = ops.Act(torch.randn((1, h, w, c1), device=dev, dtype=dt), c1)
-        x2 = ops.Act(torch.randn((1, h, w, c2), device=dev, dtype=dt), c2) if c2 else None
+        x = ops.Act(torch.randn((a.n, h, w, c1), device=dev, dtype=dt), c1)
+        x2 = ops.Act(torch.randn((a.n, h, w, c2), device=dev, dtype=dt), c2) if c2 else None
         pro = None
         if a.prologue:
-            pro = (torch.rand((1, c1 + c2), device=dev) + 0.5, torch.randn((1, c1 + c2), device=dev) * 0.1)
-        y = conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats)
+            pro = (torch.rand((a.n, c1 + c2), device=dev) + 0.5, torch.randn((a.n, c1 + c2), device=dev) * 0.1)
+        ho, wo = (2 * h, 2 * w) if ups else (h, w)
+        res = ops.Act(torch.randn((a.n, ho, wo, co), device=dev, dtype=dt), co) if a.res else None
+        y = conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats, residual=res)
         torch.cuda.synchronize()
         ts = []
         for _ in range(a.iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats, out=y)
+            conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats, out=y, residual=res)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
-        ho, wo = (2 * h, 2 * w) if ups else (h, w)
-        fl = 2.0 * k * k * (c1 + c2) * co * ho * wo
+        fl = 2.0 * k * k * (c1 + c2) * co * ho * wo * a.n
         t = sorted(ts)[len(ts) // 2]
-        print(f"{name:22s} {a.dtype} pro={int(a.prologue)} st={int(a.stats)}  {t:8.3f} ms  {fl / t / 1e9:8.1f} TFLOP/s  ({fl / 1e9:.0f} GFLOP)", flush=True)
+        if os.environ.get("ELVIS_STAMP") and y.stats is not None:
+            torch.cuda.synchronize()
+            st = y.stats.view(-1, co, 2)[:, :3, :].reshape(-1, 6).double()
+            m = st[:, :4].mean(0).tolist(); md = st[:, :4].median(0).values.tolist()
+            print(f"  stamps (cycles, mean/median over {st.shape[0]} WGs): prologue {m[0]:.0f}/{md[0]:.0f}  loop {m[1]:.0f}/{md[1]:.0f}  "
+                  f"epilogue {m[2]:.0f}/{md[2]:.0f}  store-drain {m[3]:.0f}/{md[3]:.0f}")
+        print(f"{name:22s} {a.dtype} pro={int(a.prologue)} st={int(a.stats)} res={int(a.res)}  {t:8.3f} ms  {fl / t / 1e9:8.1f} TFLOP/s  ({fl / 1e9:.0f} GFLOP)", flush=True)
 
 if __name__ == "__main__":
     main()
