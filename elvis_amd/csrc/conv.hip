@@ -1084,21 +1084,24 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
 // 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
 // (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
 constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TY_PRO128 = 12, HALO_TX = 32;
-constexpr int HALO_TY2 = 6;   // 256-thread, two-workgroups-per-CU variant (f16, 128-channel tile, 3x3)
+// 256-thread variant, two or three workgroups per CU (f16; 3x3 and sub-pixel 2x2; 128- or 64-channel tile):
+// 6 x 32 pixels x 128 channels (96px x 64co per wave) or 8 x 32 x 64 (64px x 64co per wave)
+constexpr int halo_ty2(int tco) { return tco == 128 ? 6 : 8; }
 // 1x1 convs are HBM/latency-bound: the 8-row tile halves LDS and registers so two workgroups fit a CU
 // the fused-prologue kernel with a 128-channel tile uses 12 rows (64co x 96px per wave, ~210 VGPRs)
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
 // two-workgroups-per-CU variant: f16, 3x3, 128-channel tile, LDS footprint <= 80 KB
 inline bool halo_two(const elvis_conv_desc* d) {
     static const int mode = getenv("ELVIS_HALO2") ? atoi(getenv("ELVIS_HALO2")) : 1;   // 0 disables (A/B runs)
-    if (!mode || d->ksize != 3 || d->dtype != ELVIS_F16 || choose_tile(d->cout).tco != 128) return false;
-    if (mode == 2 && !d->prologue) return false;
+    const int tco = choose_tile(d->cout).tco, ks = d->ksize;
+    if (!mode || (ks != 3 && ks != 2) || d->dtype != ELVIS_F16 || tco < 64) return false;
+    if (mode == 2 && (ks != 3 || tco != 128)) return false;
     int nkc = (d->cin + 31) / 32 + (d->cin2 > 0 ? (d->cin2 + 31) / 32 : 0);
-    size_t lds = (size_t)(HALO_TY2 + 2) * (HALO_TX + 2) * 64 + 2 * 3 * 128 * 64 + (d->prologue ? (size_t)nkc * 256 : 0);
+    size_t lds = (size_t)(halo_ty2(tco) + ks - 1) * (HALO_TX + ks - 1) * 64 + 2 * ks * (size_t)tco * 64 + (d->prologue ? (size_t)nkc * 256 : 0);
     return lds <= 80 * 1024;
 }
 inline int halo_ty(const elvis_conv_desc* d) {
-    if (halo_two(d)) return HALO_TY2;
+    if (halo_two(d)) return halo_ty2(choose_tile(d->cout).tco);
     if (d->ksize == 3 && d->prologue && choose_tile(d->cout).tco == 128) return HALO_TY_PRO128;
     return (d->prologue || d->ksize == 1) ? HALO_TY_PRO : HALO_TY;
 }
@@ -1141,17 +1144,12 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return ELVIS_OK;
 }
 
-template <typename T, int TCO, bool PRO, int KS> size_t halo2_lds(int nkc) {
-    return (size_t)((HALO_TY2 + KS - 1) * (HALO_TX + KS - 1) * 64) + 2 * KS * (size_t)TCO * 64 +
-           (PRO ? (size_t)nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
-}
-
 template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     if constexpr (!ACT) {
         if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true>(a, stream);
     }
     constexpr bool TWO = NT == 256;
-    constexpr int TY = TWO ? HALO_TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
+    constexpr int TY = TWO ? halo_ty2(TCO) : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
     const size_t lds_fixed = (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
@@ -1174,10 +1172,11 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false>
 
 template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
     if (a.ksize == 1) return launch_halo_p<T, TCO, false, 1>(a, stream);
-    if (a.ksize == 2) return launch_halo_p<T, TCO, false, 2>(a, stream);
-    if constexpr (TCO == 128 && sizeof(T) == 2) {
+    if constexpr (TCO >= 64 && sizeof(T) == 2) {
+        if (a.two && a.ksize == 2) return launch_halo_p<T, TCO, false, 2, 256>(a, stream);
         if (a.two) return a.prologue ? launch_halo_p<T, TCO, true, 3, 256>(a, stream) : launch_halo_p<T, TCO, false, 3, 256>(a, stream);
     }
+    if (a.ksize == 2) return launch_halo_p<T, TCO, false, 2>(a, stream);
     return a.prologue ? launch_halo_p<T, TCO, true, 3>(a, stream) : launch_halo_p<T, TCO, false, 3>(a, stream);
 }
 
