@@ -350,9 +350,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // the halo is single-buffered (next chunk staged in registers, written between two barriers) and
     // the weight ring has two row slots (slot = row step parity).
     constexpr bool TWO = NT == 256;
-    static_assert(!(TWO && KS == 1), "the 1x1 path keeps the 512-thread layout");
     constexpr int NSLOT = (TWO || KS == 2) ? 2 : 3;   // weight ring slots; row step r uses slot r % NSLOT
     constexpr int NHB = TWO ? 1 : 2;                  // halo buffers
+    // G1 (1x1 conv / linear layer, 256 threads): a plain K-loop GEMM, HBM-bound.  Both operands go
+    // global -> LDS by LDS-DMA through a ring of G1_NST stages ([pixel tile | weight slice] per
+    // 64-byte K chunk), G1_NST-1 chunks in flight, one barrier per chunk, counted vmcnt.  Needs
+    // cin (and cin2) to be whole K chunks: the DMA cannot zero-fill channel padding.
+    constexpr bool G1 = TWO && KS == 1;
+    constexpr int G1_NST = 3;
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
@@ -382,8 +387,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         long long xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+#ifdef ELVIS_EXP_COSLOW   /* experiment: co-tile slowest (each XCD streams one co-tile's weights) */
+    const long long ntile_ = (long long)p.tiles_x * p.tiles_y * p.n;
+    const int co_tile = (int)(bid / ntile_);
+    long long t = bid % ntile_;
+#else
     const int co_tile = (int)(bid % p.n_co_tiles);
     long long t = bid / p.n_co_tiles;
+#endif
     const int tx = (int)(t % p.tiles_x);
     t /= p.tiles_x;
     const int ty = (int)(t % p.tiles_y);
@@ -662,6 +673,73 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         }
     }
 
+#ifdef ELVIS_EXP_STAMP
+    unsigned long long stamp1 = 0;
+#endif
+    if constexpr (G1) {
+        constexpr int STAGE = HALO_BYTES + W_TAP_BYTES;
+        constexpr int L = H_PER + W_PER;   // LDS-DMA instructions per thread per stage
+        static_assert(HCH % NT == 0 && W_CHUNKS % NT == 0, "G1 stages are whole 1 KiB wave pieces");
+        const int swz_t = ((tid >> 4) & 1) << 1;   // (pix >> 2) & 1 of every piece this thread stages
+        const int wave_u1 = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);
+        auto g1_dma = [&](const char* src, unsigned dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        };
+        auto g1_issue = [&](int kc) {
+            const int slot = kc % G1_NST;
+            const bool second = kc >= p.nkc1;
+            const char* xsrc = (const char*)(second ? p.x2 : p.x);
+            const long long pitch = second ? p.cin2_pitch : p.cin_pitch;
+            const int c0 = (second ? kc - p.nkc1 : kc) * KC + ((q4 ^ swz_t) * VEC);   // source chunk of LDS slot q4
+#pragma unroll
+            for (int i = 0; i < H_PER; ++i)
+                g1_dma(xsrc + ((long long)h_src[i] * pitch + c0) * (long long)sizeof(T),
+                       lds0 + (unsigned)(slot * STAGE + (i * NT + wave_u1 * 64) * 16));
+            const char* wsrc = (const char*)p.w + ((long long)kc * p.co_pad + co0) * 64;
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i)
+                g1_dma(wsrc + wl_off[i], lds0 + (unsigned)(slot * STAGE + HALO_BYTES + (i * NT + wave_u1 * 64) * 16));
+        };
+#pragma unroll
+        for (int s = 0; s < G1_NST - 1; ++s)
+            if (s < nkc) g1_issue(s);
+        const int pp0 = (w_px * ROWS) * HX + lr;
+        int bb[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int carry = ((pp0 & 3) + r) >> 2;
+                int bit = ((pp0 >> 2) & 1) ^ carry ^ e;
+                bb[r][e] = pp0 * 64 + ((lq ^ (bit << 1)) << 4);
+            }
+        const int a_off = HALO_BYTES + w_co * WCO * 1024 + lane_off;
+#ifdef ELVIS_EXP_STAMP
+        stamp1 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int kc = 0; kc < nkc; ++kc) {
+            // this thread's pieces of chunk kc have landed when at most the younger chunks' DMAs remain
+            if (kc + G1_NST - 2 < nkc) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G1_NST - 2) * L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // everyone's pieces landed; everyone is past its reads of chunk kc-1
+            if (kc + G1_NST - 1 < nkc) g1_issue(kc + G1_NST - 1);
+            const int sb = (kc % G1_NST) * STAGE;
+            frag_t fa[WCO];
+#pragma unroll
+            for (int i = 0; i < WCO; ++i) fa[i] = *reinterpret_cast<const frag_t*>(smem + sb + a_off + i * 1024);
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) {
+                const int C = (j >> 1) * HX + (j & 1) * 16;
+                frag_t fb = *reinterpret_cast<const frag_t*>(smem + sb + bb[C & 3][(C >> 2) & 1] + C * 64);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);
+            }
+        }
+        __syncthreads();   // the epilogue reuses LDS for the statistics reduction
+    } else {
     // ---- prologue: halo(0) and weight row 0 into LDS; weight row 1 in flight in registers.
     // The first global loads are issued before the prologue table is built so their latency
     // overlaps it (one workgroup per CU: nothing else hides a workgroup's start-up).
@@ -693,7 +771,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     __syncthreads();
 
 #ifdef ELVIS_EXP_STAMP
-    const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
+    stamp1 = __builtin_amdgcn_s_memtime();
 #endif
     // B-fragment addressing with ZERO per-read VALU.  A lane reads halo pixel x + C (x = its pixel at
     // tap (0,0) of the wave's first sub-tile, C a compile-time pixel offset) at byte
@@ -733,6 +811,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #else
 #define ELVIS_STAGE_H(x) ELVIS_STAGE(x)
 #endif
+#ifdef ELVIS_EXP_SETPRIO
+#define ELVIS_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define ELVIS_SETPRIO(x)
+#endif
 #ifdef ELVIS_EXP_NOBARRIER /* timing experiment only */
 #define ELVIS_BARRIER()
 #else
@@ -760,6 +843,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 const int C = DY * HX;                                                                 \
                 fb[0] = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64);     \
             }                                                                                          \
+            ELVIS_SETPRIO(1);                                                                          \
             _Pragma("unroll") for (int s = 0; s < KS * WPX; ++s) {                                     \
                 const int dx = s / WPX, j = s - dx * WPX;                                              \
                 if (s + 1 < KS * WPX) {                                                                \
@@ -775,6 +859,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                         if (pi * 6 / (2 * H_PER) == (DY - 1) * 3 + dx) { ELVIS_STAGE(halo_act(kcn, pi / 2, pi & 1);) } \
                 }                                                                                      \
             }                                                                                          \
+            ELVIS_SETPRIO(0);                                                                          \
             __builtin_amdgcn_sched_group_barrier(0x100, WCO + 1, 0);                                   \
             _Pragma("unroll") for (int s = 0; s < KS * WPX; ++s) {                                     \
                 if ((s % WPX) < WCO && s / WPX + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); \
@@ -868,6 +953,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         }
     }
 #undef ELVIS_ROW_STEP
+    }   // !G1
 #ifdef ELVIS_EXP_STAMP
     const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1100,6 +1186,12 @@ inline bool halo_two(const elvis_conv_desc* d) {
     size_t lds = (size_t)(halo_ty2(tco) + ks - 1) * (HALO_TX + ks - 1) * 64 + 2 * ks * (size_t)tco * 64 + (d->prologue ? (size_t)nkc * 256 : 0);
     return lds <= 80 * 1024;
 }
+// 1x1 GEMM path with LDS-DMA staging: f16, whole 32-channel K chunks, 64/128-channel tile
+inline bool halo_g1(const elvis_conv_desc* d) {
+    static const int on = getenv("ELVIS_G1") ? atoi(getenv("ELVIS_G1")) : 1;   // 0 disables (A/B runs)
+    return on && d->ksize == 1 && d->dtype == ELVIS_F16 && choose_tile(d->cout).tco >= 64 && d->cin % 32 == 0 &&
+           d->cin2 % 32 == 0;
+}
 inline int halo_ty(const elvis_conv_desc* d) {
     if (halo_two(d)) return halo_ty2(choose_tile(d->cout).tco);
     if (d->ksize == 3 && d->prologue && choose_tile(d->cout).tco == 128) return HALO_TY_PRO128;
@@ -1149,8 +1241,9 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false>
         if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true>(a, stream);
     }
     constexpr bool TWO = NT == 256;
-    constexpr int TY = TWO ? halo_ty2(TCO) : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
-    const size_t lds_fixed = (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
+    constexpr int TY = (TWO && KS == 1) ? HALO_TY_PRO : TWO ? halo_ty2(TCO) : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
+    const size_t lds_fixed = (TWO && KS == 1) ? 3 * ((size_t)TY * HALO_TX * 64 + (size_t)TCO * 64)
+                           : (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
     static bool attr_set = false;
@@ -1171,6 +1264,9 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false>
 }
 
 template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t stream) {
+    if constexpr (TCO >= 64 && sizeof(T) == 2) {
+        if (a.two && a.ksize == 1) return launch_halo_p<T, TCO, false, 1, 256>(a, stream);
+    }
     if (a.ksize == 1) return launch_halo_p<T, TCO, false, 1>(a, stream);
     if constexpr (TCO >= 64 && sizeof(T) == 2) {
         if (a.two && a.ksize == 2) return launch_halo_p<T, TCO, false, 2, 256>(a, stream);
@@ -1262,7 +1358,7 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
     TileCfg c = choose_tile(d->cout);
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         const bool pro = d->ksize == 3 && d->prologue;
-        snprintf(buf, n, "conv3x3_halo_kernel<%s,%d,%d,%d,%s,%d,%s>", t, c.tco, halo_two(d) ? 256 : 512, halo_ty(d),
+        snprintf(buf, n, "conv3x3_halo_kernel<%s,%d,%d,%d,%s,%d,%s>", t, c.tco, (halo_two(d) || halo_g1(d)) ? 256 : 512, halo_ty(d),
                  pro ? "true" : "false", d->ksize, d->act ? "true" : "false");
     } else {
         static const int cfg[4][4] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 4, 1, 4}, {1, 4, 1, 4}};
@@ -1300,7 +1396,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.par_b = d->ksize == 2 ? (d->subpixel - 1) & 1 : 0;
     a.tiles_x = ((d->ksize == 2 ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
     const int tyv = halo_ty(d);
-    a.two = halo_two(d) ? 1 : 0;
+    a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + tyv - 1) / tyv;
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
