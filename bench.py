@@ -199,8 +199,17 @@ def main():
         tot_fl = sum(a[0] for a in agg.values())
         tot_s = sum(a[1] for a in agg.values())
         peak = PEAK_TFLOPS[args.mode]
+        # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of this same workload, tools/pmc_traffic.py); null if none is on file
+        traffic = traffic_src = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_hbm_traffic.json")
+        if os.path.exists(tpath) and args.batch == 6 and (args.height, args.width) == (1080, 1920):
+            rec = json.load(open(tpath))["kernels"].get(name)
+            if rec:
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_d_hbm_traffic.json (PMC, separate passes)"
         roof = {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": fl / sec / 1e12 / peak, "traffic": None, "launches": cnt,
+                "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src, "launches": cnt,
                 "avg_launch_ms": sec / cnt * 1e3, "flop_per_launch_avg": fl / cnt,
                 "all_conv_kernels": {"achieved": tot_fl / tot_s / 1e12, "time_share_of_step": tot_s / elapsed,
                                      "tflop_per_frame": tot_fl / (args.steps * F) / 1e12}}
