@@ -356,6 +356,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // global -> LDS by LDS-DMA through a ring of G1_NST stages ([pixel tile | weight slice] per
     // 64-byte K chunk), G1_NST-1 chunks in flight, one barrier per chunk, counted vmcnt.  Needs
     // cin (and cin2) to be whole K chunks: the DMA cannot zero-fill channel padding.
+#ifndef ELVIS_TWO_WDMA
+#define ELVIS_TWO_WDMA 1
+#endif
+    // weights of the 256-thread kernels: LDS-DMA (no staging registers) or register staging
+    constexpr bool WDMA = TWO && ELVIS_TWO_WDMA;
     constexpr bool G1 = TWO && KS == 1;
     constexpr int G1_NST = 3;
     constexpr int HCH = HP * 4;
@@ -434,7 +439,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // loaded at tap 3, stored at tap 5.
     constexpr int HA = (H_PER + 1) / 2;
     uint4 hreg[H_PER];
-    uint4 wr0[W_PER], wr1[W_PER], wr2[W_PER];   // the three taps of the NEXT kernel row
 
     int wl_off[W_PER];
 #pragma unroll
@@ -509,27 +513,39 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             *reinterpret_cast<uint4*>(halo + buf * HALO_BYTES + lds_row_off(chunk >> 2, chunk & 3)) = v;
     };
     // row step r = kc*3 + dy: the three taps (dy, 0..2) of K chunk kc
-    auto w_load1 = [&](const char* wsrc, uint4 (&wr)[W_PER]) {
-#pragma unroll
-        for (int i = 0; i < W_PER; ++i) {
-            int chunk = tid + i * NT;
-            if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS) wr[i] = *reinterpret_cast<const uint4*>(wsrc + chunk * 16);
-        }
-    };
+    // (named registers, not arrays passed by reference: those end up in scratch)
+    static_assert(W_PER <= 2, "weight staging holds at most two 16-byte chunks per thread per tap");
+    constexpr bool W_FULL0 = W_CHUNKS >= NT, W_FULL1 = W_PER == 2 && W_CHUNKS >= 2 * NT;
+    const bool w_ok0 = W_FULL0 || tid < W_CHUNKS, w_ok1 = W_PER == 2 && (W_FULL1 || tid + NT < W_CHUNKS);
+    uint4 wr00 = {}, wr01 = {}, wr10 = {}, wr11 = {}, wr20 = {}, wr21 = {};
     auto w_load = [&](int r) {
         r = r < nrows ? r : nrows - 1;   // tail rows re-load the last slice (never consumed)
         int kc = r / KS, dy = r - kc * KS;
         const long long tap_stride = (long long)nkc * p.co_pad * 64;
         const char* wsrc = (const char*)p.w + ((long long)(dy * KS * nkc + kc) * p.co_pad + co0) * 64;
-        w_load1(wsrc, wr0);
-        if (KS >= 2) w_load1(wsrc + tap_stride, wr1);
-        if (KS == 3) w_load1(wsrc + 2 * tap_stride, wr2);
+        const int o0 = (w_ok0 ? tid : 0) * 16, o1 = (w_ok1 ? tid + NT : 0) * 16;   // clamped: branch-free
+        wr00 = *reinterpret_cast<const uint4*>(wsrc + o0);
+        if (W_PER == 2) wr01 = *reinterpret_cast<const uint4*>(wsrc + o1);
+        if (KS >= 2) {
+            wr10 = *reinterpret_cast<const uint4*>(wsrc + tap_stride + o0);
+            if (W_PER == 2) wr11 = *reinterpret_cast<const uint4*>(wsrc + tap_stride + o1);
+        }
+        if (KS == 3) {
+            wr20 = *reinterpret_cast<const uint4*>(wsrc + 2 * tap_stride + o0);
+            if (W_PER == 2) wr21 = *reinterpret_cast<const uint4*>(wsrc + 2 * tap_stride + o1);
+        }
     };
-    auto w_store1 = [&](char* dst, const uint4 (&wr)[W_PER]) {
-#pragma unroll
-        for (int i = 0; i < W_PER; ++i) {
-            int chunk = tid + i * NT;
-            if (W_CHUNKS % NT == 0 || chunk < W_CHUNKS) *reinterpret_cast<uint4*>(dst + wl_off[i]) = wr[i];
+    auto w_store = [&](int slot) {
+        char* dst = wring + slot * W_BYTES;
+        if (w_ok0) *reinterpret_cast<uint4*>(dst + wl_off[0]) = wr00;
+        if (W_PER == 2 && w_ok1) *reinterpret_cast<uint4*>(dst + wl_off[W_PER - 1]) = wr01;
+        if (KS >= 2) {
+            if (w_ok0) *reinterpret_cast<uint4*>(dst + W_TAP_BYTES + wl_off[0]) = wr10;
+            if (W_PER == 2 && w_ok1) *reinterpret_cast<uint4*>(dst + W_TAP_BYTES + wl_off[W_PER - 1]) = wr11;
+        }
+        if (KS == 3) {
+            if (w_ok0) *reinterpret_cast<uint4*>(dst + 2 * W_TAP_BYTES + wl_off[0]) = wr20;
+            if (W_PER == 2 && w_ok1) *reinterpret_cast<uint4*>(dst + 2 * W_TAP_BYTES + wl_off[W_PER - 1]) = wr21;
         }
     };
     // TWO: weights go global -> LDS directly (LDS-DMA, no staging registers).  The DMA writes
@@ -559,12 +575,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             }
     };
     auto w_glds_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-    auto w_store = [&](int slot) {
-        char* dst = wring + slot * W_BYTES;
-        w_store1(dst, wr0);
-        if (KS >= 2) w_store1(dst + W_TAP_BYTES, wr1);
-        if (KS == 3) w_store1(dst + 2 * W_TAP_BYTES, wr2);
-    };
 
     float4v acc[WCO][WPX];
 #pragma unroll
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // The first global loads are issued before the prologue table is built so their latency
     // overlaps it (one workgroup per CU: nothing else hides a workgroup's start-up).
     halo_load(0, 0, H_PER);
-    if constexpr (TWO) w_glds(0, 0); else w_load(0);
+    if constexpr (WDMA) w_glds(0, 0); else w_load(0);
     if (PRO) {
         // table entry t = (kc*4 + q)*2*VEC + {0..VEC-1: a, VEC..2VEC-1: b}; channels past the
         // logical count get a = b = 0 (silu(0) = 0 keeps zero padding exact)
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         __syncthreads();
     }
     halo_store(0, 0, 0, H_PER);
-    if constexpr (TWO) {
+    if constexpr (WDMA) {
         w_glds_wait();
     } else {
         w_store(0);
@@ -824,10 +834,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #define ELVIS_ROW_STEP(DY)                                                                             \
     {                                                                                                  \
         const int rslot = TWO ? ((r0 + DY) & 1) : DY;                                                  \
-        if constexpr (TWO) {                                                                           \
+        if constexpr (WDMA) {                                                                          \
             ELVIS_STAGE_W(w_glds(r0 + DY + 1, rslot ^ 1);)                                             \
         } else {                                                                                       \
-            ELVIS_STAGE(w_store((DY + 1) % NSLOT);)                                                    \
+            ELVIS_STAGE(w_store(TWO ? (rslot ^ 1) : (DY + 1) % NSLOT);)                                \
             ELVIS_STAGE(w_load(r0 + DY + 2);)                                                          \
         }                                                                                              \
         ELVIS_STAGE_H(if (DY == 0) halo_load(kcn, 0, PRO ? H_PER : HA);)                               \
@@ -896,7 +906,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         }                                                                                              \
         ELVIS_STAGE(if (DY == 0 && !PRO && !TWO) halo_store(kcn, (kc + 1) & 1, 0, HA);)                \
         ELVIS_STAGE(if (DY == 1 && !PRO && !TWO) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)            \
-        if constexpr (TWO) { ELVIS_STAGE_W(w_glds_wait();) }                                           \
+        if constexpr (WDMA) { ELVIS_STAGE_W(w_glds_wait();) }                                          \
         ELVIS_BARRIER();                                                                               \
     }
     for (int kc = 0; kc < nkc; ++kc) {
