@@ -1175,7 +1175,8 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
     bool same = d->ho == (d->upsample ? 2 * d->h : d->h) && d->wo == (d->upsample ? 2 * d->w : d->w);
     if (d->ksize == 3) return d->stride == 1 && d->pad_before == 1 && same;
     return d->ksize == 1 && d->stride == 1 && d->pad_before == 0 && same && !d->prologue &&
-           (long long)d->n * d->ho * d->wo >= 4096;   // tiny GEMMs (load-time embeddings) stay on the generic kernel
+           (long long)d->ho * d->wo >= 256;   // tiny GEMMs (load-time embeddings) stay on the generic kernel; the choice
+                                              // must not depend on n: the two kernels round differently (bias first / last)
 }
 // 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
 // (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
