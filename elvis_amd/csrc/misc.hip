@@ -104,17 +104,24 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const T* __restrict__ z
                                                          const float* __restrict__ codebook, int n_embed) {
     constexpr int CHUNK = 256;   // codes per part per LDS stage
     constexpr int MAXC = 4;
+    constexpr int PPT = 4;       // pixels per thread: every staged code is applied to 4 pixels
     __shared__ float cb[4 * CHUNK * MAXC];
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long px = t >> 2;
+    const long long px0 = (t >> 2) * PPT;
     const int part = (int)(t & 3);
-    const bool active = px < pixels;
     const int Q = (n_embed + 3) / 4;
-    float zv[MAXC];
+    float zv[PPT][MAXC];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) zv[k] = (active && k < c) ? to_f(z[px * pitch_in + k]) : 0.f;
-    float best = 3.0e38f;
-    int best_i = 0x7fffffff;
+    for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) zv[q][k] = (px0 + q < pixels && k < c) ? to_f(z[(px0 + q) * pitch_in + k]) : 0.f;
+    float best[PPT];
+    int best_i[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        best[q] = 3.0e38f;
+        best_i[q] = 0x7fffffff;
+    }
     for (int base = 0; base < Q; base += CHUNK) {
         __syncthreads();
         // stage codes [p*Q + base, p*Q + base + CHUNK) of every part p
@@ -128,32 +135,45 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const T* __restrict__ z
         const float* my = cb + part * CHUNK * MAXC;
         const int first = part * Q + base;
         for (int e = 0; e < CHUNK; ++e) {
-            float d = 0.f;
-            for (int k = 0; k < c; ++k) {
-                float df = __fsub_rn(zv[k], my[e * MAXC + k]);
-                float sq = __fmul_rn(df, df);
-                d = k == 0 ? sq : __fadd_rn(d, sq);
-            }
-            if (d < best) {
-                best = d;
-                best_i = first + e;
-            }
-        }
-    }
-    // lexicographic (distance, index) min over the 4 lanes of the pixel
+            float cv[MAXC];
 #pragma unroll
-    for (int o = 1; o < 4; o <<= 1) {
-        float od = __shfl_xor(best, o, 64);
-        int oi = __shfl_xor(best_i, o, 64);
-        if (od < best || (od == best && oi < best_i)) {
-            best = od;
-            best_i = oi;
+            for (int k = 0; k < MAXC; ++k) cv[k] = k < c ? my[e * MAXC + k] : 0.f;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) {
+                    if (k < c) {
+                        float df = __fsub_rn(zv[q][k], cv[k]);
+                        float sq = __fmul_rn(df, df);
+                        d = k == 0 ? sq : __fadd_rn(d, sq);
+                    }
+                }
+                if (d < best[q]) {
+                    best[q] = d;
+                    best_i[q] = first + e;
+                }
+            }
         }
     }
-    if (active && part == 0) {
-        if (idx_out) idx_out[px] = best_i;
-        for (int k = 0; k < c; ++k) zq[px * pitch_out + k] = from_f<T>(codebook[(long long)best_i * c + k]);
-        for (int k = c; k < pitch_out; ++k) zq[px * pitch_out + k] = from_f<T>(0.f);
+    // lexicographic (distance, index) min over the 4 lanes of the pixel group
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            float od = __shfl_xor(best[q], o, 64);
+            int oi = __shfl_xor(best_i[q], o, 64);
+            if (od < best[q] || (od == best[q] && oi < best_i[q])) {
+                best[q] = od;
+                best_i[q] = oi;
+            }
+        }
+        const long long px = px0 + q;
+        if (px < pixels && part == 0) {
+            if (idx_out) idx_out[px] = best_i[q];
+            for (int k = 0; k < c; ++k) zq[px * pitch_out + k] = from_f<T>(codebook[(long long)best_i[q] * c + k]);
+            for (int k = c; k < pitch_out; ++k) zq[px * pitch_out + k] = from_f<T>(0.f);
+        }
     }
 }
 
@@ -267,7 +287,7 @@ extern "C" int elvis_vq_nearest(const void* z, void* zq, int32_t* idx_out, int d
                                 elvis_stream_t stream) {
     ELVIS_REQUIRE(z && zq && codebook && pixels > 0 && n_embed > 0, "elvis_vq_nearest: bad argument");
     ELVIS_REQUIRE(c >= 1 && c <= 4 && pitch_in >= c && pitch_out >= c, "elvis_vq_nearest: c must be 1..4");
-    int grid = (int)((pixels * 4 + 255) / 256);
+    int grid = (int)((((pixels + 3) / 4) * 4 + 255) / 256);   // 4 lanes per group of 4 pixels
     if (dtype == ELVIS_F16)
         hipLaunchKernelGGL(vq_nearest_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)z,
                            (half_t*)zq, idx_out, pixels, c, pitch_in, pitch_out, codebook, n_embed);
