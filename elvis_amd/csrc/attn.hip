@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const T* __restri
 //                                        reduced with DPP/shuffle xor 1,2,4,8
 //   O[i][d] = sum_j P[i][j] V[j][d]      16 MFMAs; P goes through a per-wave LDS tile to become an A
 //                                        operand (row = token, k = key contiguous), V through a
-//                                        padded LDS tile read transposed (k = key, col = d)
+//                                        LDS tile stored transposed ([d][key]): one ds_read_b128 per fragment
 constexpr int P_PITCH = NTOK + 8;   // halfs; 144-byte rows keep ds_read_b128 16-byte aligned
-constexpr int V_PITCH = HD + 1;     // halfs; odd pitch spreads the transposed 2-byte reads over banks
+constexpr int V_PITCH = NTOK + 8;   // halfs; V is kept TRANSPOSED ([d][key], 144-byte rows) so a B fragment is one ds_read_b128
 
 __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t* __restrict__ qkv,
                                                                     half_t* __restrict__ out, int h, int w,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t
                                                                     const float* __restrict__ bias_table,
                                                                     float scale) {
     __shared__ __attribute__((aligned(16))) half_t sP[4][NTOK * P_PITCH];
-    __shared__ half_t sV[4][NTOK * V_PITCH];
+    __shared__ __attribute__((aligned(16))) half_t sV[4][HD * V_PITCH];
     __shared__ float sBias[4][(2 * WS - 1) * (2 * WS - 1)];
     __shared__ int s_pos[NTOK];
     __shared__ int s_region[NTOK];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t
             int j = t >> 2, c = t & 3;
             half8 v8 = *reinterpret_cast<const half8*>(qkv + (long long)s_pos[j] * qkv_pitch + 2 * E + head * HD + c * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) myV[j * V_PITCH + c * 8 + e] = v8[e];
+            for (int e = 0; e < 8; ++e) myV[(c * 8 + e) * V_PITCH + j] = v8[e];
         }
         // Q (A operand) and K (B operand) fragments straight from global memory
         half8 fq[4], fk[4];
@@ -201,17 +201,15 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t
                     v[jt] = a;
                     mx = fmaxf(mx, a);
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                mx = row16_max(mx);   // the 16 lanes holding a row's columns are one DPP row
                 float sum = 0.f;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     v[jt] = __expf(v[jt] - mx);
                     sum += v[jt];
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-                const float inv = 1.0f / sum;
+                sum = row16_sum(sum);
+                const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) myP[i * P_PITCH + jt * 16 + lr] = (half_t)(v[jt] * inv);
             }
@@ -229,8 +227,7 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t
             half8 fv[2];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) fv[dt][e] = myV[(ks * 32 + lq * 8 + e) * V_PITCH + dt * 16 + lr];
+                fv[dt] = *reinterpret_cast<const half8*>(myV + (dt * 16 + lr) * V_PITCH + ks * 32 + lq * 8);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 half8 fp = *reinterpret_cast<const half8*>(myP + (it * 16 + lr) * P_PITCH + ks * 32 + lq * 8);
@@ -239,16 +236,28 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t
                     oacc[it][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fp, fv[dt], oacc[it][dt], 0, 0, 0);
             }
         }
-        // store: lane holds O[i = it*16 + lq*4 + r][d = dt*16 + lr]
+        // store: lane holds O[i = it*16 + lq*4 + r][d = dt*16 + lr].  Transpose through the (now idle) P
+        // tile so that every token's 64-byte head slice leaves as four 16-byte stores, not 32 2-byte ones.
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's P reads are done
+        __builtin_amdgcn_wave_barrier();
+        constexpr int O_PITCH = HD + 8;       // halfs; 80-byte rows: 16-byte aligned chunks
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = it * 16 + lq * 4 + r;
-                half_t* dst = out + (long long)s_pos[i] * out_pitch + head * HD;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) dst[dt * 16 + lr] = (half_t)oacc[it][dt][r];
+                for (int dt = 0; dt < 2; ++dt) myP[i * O_PITCH + dt * 16 + lr] = (half_t)oacc[it][dt][r];
             }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pc = lane + 64 * k, tok = pc >> 2, c8 = pc & 3;
+            *reinterpret_cast<half8*>(out + (long long)s_pos[tok] * out_pitch + head * HD + c8 * 8) =
+                *reinterpret_cast<const half8*>(myP + tok * O_PITCH + c8 * 8);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();   // the next head reuses this wave's LDS tiles
     }
 }
