@@ -43,7 +43,7 @@ struct ConvArgs {
     int n_co_tiles;
     long long n_px_tiles;
     // halo kernel only
-    int two;              // 256-thread two-workgroups-per-CU variant
+    int two, tall;        // 256-thread two-workgroups-per-CU variant; its 16-row form
     float* stats;         // [n*tiles_y*tiles_x][cout][2] partial (sum, sumsq) or null
     int tiles_x, tiles_y;
     int sub, par_a, par_b;   // sub-pixel mode (KS == 2): output pixel (2y+par_a, 2x+par_b)
@@ -347,6 +347,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // global -> LDS by LDS-DMA through a ring of G1_NST stages ([pixel tile | weight slice] per
     // 64-byte K chunk), G1_NST-1 chunks in flight, one barrier per chunk, counted vmcnt.  Needs
     // cin (and cin2) to be whole K chunks: the DMA cannot zero-fill channel padding.
+#ifndef ELVIS_COUNTED_W
+#define ELVIS_COUNTED_W 1
+#endif
 #ifndef ELVIS_TWO_WDMA
 #define ELVIS_TWO_WDMA 1
 #endif
@@ -855,10 +858,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 if (dx + 1 < KS && j < WCO)                                                            \
                     fa[(dx + 1) & 1][j] = *reinterpret_cast<const frag_t*>(wsb + (dx + 1) * W_TAP_BYTES + j * 1024); \
                 _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[dx & 1][i], fb[s & 1]); \
-                if (PRO && DY >= 1 && j == WPX / 2 - 1) {                                              \
-                    _Pragma("unroll") for (int pi = 0; pi < 2 * H_PER; ++pi)                           \
-                        if (pi * 6 / (2 * H_PER) == (DY - 1) * 3 + dx) { ELVIS_STAGE(halo_act(kcn, pi / 2, pi & 1);) } \
-                }                                                                                      \
             }                                                                                          \
             ELVIS_SETPRIO(0);                                                                          \
             __builtin_amdgcn_sched_group_barrier(0x100, WCO + 1, 0);                                   \
@@ -897,7 +896,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         }                                                                                              \
         ELVIS_STAGE(if (DY == 0 && !PRO && !TWO) halo_store(kcn, (kc + 1) & 1, 0, HA);)                \
         ELVIS_STAGE(if (DY == 1 && !PRO && !TWO) halo_store(kcn, (kc + 1) & 1, HA, H_PER);)            \
-        if constexpr (WDMA) { ELVIS_STAGE_W(w_glds_wait();) }                                          \
+        if constexpr (WDMA) {                                                                          \
+            /* retire the weight DMAs only: the halo loads of this row were issued AFTER them (younger), \
+               so a counted wait leaves those HBM loads in flight across the barrier */                \
+            constexpr int YOUNGER = ELVIS_COUNTED_W ? (DY == 0 ? (PRO ? H_PER : HA) : (DY == 1 && !PRO) ? H_PER - HA : 0) : 0; \
+            ELVIS_STAGE_W(asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");)            \
+        }                                                                                              \
         ELVIS_BARRIER();                                                                               \
     }
     for (int kc = 0; kc < nkc; ++kc) {
@@ -935,12 +939,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             // overwrite the single buffer with the register-staged next chunk
 #ifndef ELVIS_EXP_NOH
             if (kc + 1 < nkc) {
-                if (PRO) {
-#pragma unroll
-                    for (int i = 0; i < H_PER; ++i) halo_write(kcn, 0, i);
-                } else {
-                    halo_store(kcn, 0, 0, H_PER);
-                }
+                // (with the prologue: GroupNorm-affine + SiLU applied here, in one block between the two
+                // barriers - keeping its LDS table reads out of the row steps leaves their fragment
+                // pipeline intact; the CU's other workgroup runs MFMAs meanwhile)
+                halo_store(kcn, 0, 0, H_PER);
             }
 #endif
             __syncthreads();
@@ -1174,7 +1176,14 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
 constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TY_PRO128 = 12, HALO_TX = 32;
 // 256-thread variant, two or three workgroups per CU (f16; 3x3 and sub-pixel 2x2; 128- or 64-channel tile):
 // 6 x 32 pixels x 128 channels (96px x 64co per wave) or 8 x 32 x 64 (64px x 64co per wave)
-constexpr int halo_ty2(int tco) { return tco == 128 ? 6 : 8; }
+// 8 x 32 pixel tiles; the 64-channel tile with the fused prologue uses 16 rows on large images (128 px x
+// 64 cout per wave: better fragment reuse), 8 rows where a taller tile would leave CUs without work
+constexpr int HALO_TY2 = 8, HALO_TY2_TALL = 16;
+inline bool halo_tall(const elvis_conv_desc* d) {
+    return d->ksize == 3 && d->prologue && choose_tile(d->cout).tco == 64 &&
+           (long long)d->ho * d->wo >= 128 * 1024;   // per image, NOT per batch: the tile shape sets the statistics' summation order
+}
+inline int halo_ty2(const elvis_conv_desc* d) { return halo_tall(d) ? HALO_TY2_TALL : HALO_TY2; }
 // 1x1 convs are HBM/latency-bound: the 8-row tile halves LDS and registers so two workgroups fit a CU
 // the fused-prologue kernel with a 128-channel tile uses 12 rows (64co x 96px per wave, ~210 VGPRs)
 inline int kc_elems(int dtype) { return dtype == ELVIS_F16 ? 32 : 16; }
@@ -1185,7 +1194,7 @@ inline bool halo_two(const elvis_conv_desc* d) {
     if (!mode || (ks != 3 && ks != 2) || d->dtype != ELVIS_F16 || tco < 64) return false;
     if (mode == 2 && (ks != 3 || tco != 128)) return false;
     int nkc = (d->cin + 31) / 32 + (d->cin2 > 0 ? (d->cin2 + 31) / 32 : 0);
-    size_t lds = (size_t)(halo_ty2(tco) + ks - 1) * (HALO_TX + ks - 1) * 64 + 2 * ks * (size_t)tco * 64 + (d->prologue ? (size_t)nkc * 256 : 0);
+    size_t lds = (size_t)(halo_ty2(d) + ks - 1) * (HALO_TX + ks - 1) * 64 + 2 * ks * (size_t)tco * 64 + (d->prologue ? (size_t)nkc * 256 : 0);
     return lds <= 80 * 1024;
 }
 // 1x1 GEMM path with LDS-DMA staging: f16, whole 32-channel K chunks, 64/128-channel tile
@@ -1195,7 +1204,7 @@ inline bool halo_g1(const elvis_conv_desc* d) {
            d->cin2 % 32 == 0;
 }
 inline int halo_ty(const elvis_conv_desc* d) {
-    if (halo_two(d)) return halo_ty2(choose_tile(d->cout).tco);
+    if (halo_two(d)) return halo_ty2(d);
     if (d->ksize == 3 && d->prologue && choose_tile(d->cout).tco == 128) return HALO_TY_PRO128;
     return (d->prologue || d->ksize == 1) ? HALO_TY_PRO : HALO_TY;
 }
@@ -1238,12 +1247,12 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return ELVIS_OK;
 }
 
-template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false, int TY2 = HALO_TY2> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     if constexpr (!ACT) {
-        if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true>(a, stream);
+        if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true, TY2>(a, stream);
     }
     constexpr bool TWO = NT == 256;
-    constexpr int TY = (TWO && KS == 1) ? HALO_TY_PRO : TWO ? halo_ty2(TCO) : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
+    constexpr int TY = (TWO && KS == 1) ? HALO_TY_PRO : TWO ? TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
     const size_t lds_fixed = (TWO && KS == 1) ? 3 * ((size_t)TY * HALO_TX * 64 + (size_t)TCO * 64)
                            : (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
@@ -1272,6 +1281,9 @@ template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t st
     if (a.ksize == 1) return launch_halo_p<T, TCO, false, 1>(a, stream);
     if constexpr (TCO >= 64 && sizeof(T) == 2) {
         if (a.two && a.ksize == 2) return launch_halo_p<T, TCO, false, 2, 256>(a, stream);
+        if constexpr (TCO == 64) {
+            if (a.two && a.prologue && a.tall) return launch_halo_p<T, TCO, true, 3, 256, false, HALO_TY2_TALL>(a, stream);
+        }
         if (a.two) return a.prologue ? launch_halo_p<T, TCO, true, 3, 256>(a, stream) : launch_halo_p<T, TCO, false, 3, 256>(a, stream);
     }
     if (a.ksize == 2) return launch_halo_p<T, TCO, false, 2>(a, stream);
@@ -1399,6 +1411,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.tiles_x = ((d->ksize == 2 ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
     const int tyv = halo_ty(d);
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
+    a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;
     a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + tyv - 1) / tyv;
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");

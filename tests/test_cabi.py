@@ -49,15 +49,15 @@ def test_argument_validation_without_gpu():
     assert h.elvis_conv2d(C.byref(d), 16, None, 16, None, None, 0, None, None, 16, None, None) == -1
     assert h.elvis_conv_stats_tiles(C.byref(d)) == 0
     d.ksize, d.pad_before, d.h, d.w, d.ho, d.wo, d.n = 3, 1, 1080, 1920, 1080, 1920, 1
-    # f16 / 128-channel tile: the 256-thread two-workgroups-per-CU kernel, 6 x 32 pixel tiles
-    assert h.elvis_conv_stats_tiles(C.byref(d)) == 180 * 60
+    # f16 / 128-channel tile: the 256-thread two-workgroups-per-CU kernel, 8 x 32 pixel tiles
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 135 * 60
     buf = C.create_string_buffer(96)
     assert h.elvis_conv_kernel_name(C.byref(d), buf, len(buf)) == 0
-    assert buf.value == b"conv3x3_halo_kernel<half,128,256,6,false,3,false>"
+    assert buf.value == b"conv3x3_halo_kernel<half,128,256,8,false,3,false>"
     d.prologue, d.act = 1, 2
-    assert h.elvis_conv_stats_tiles(C.byref(d)) == 180 * 60
+    assert h.elvis_conv_stats_tiles(C.byref(d)) == 135 * 60
     h.elvis_conv_kernel_name(C.byref(d), buf, len(buf))
-    assert buf.value == b"conv3x3_halo_kernel<half,128,256,6,true,3,true>"
+    assert buf.value == b"conv3x3_halo_kernel<half,128,256,8,true,3,true>"
     d.dtype, d.prologue, d.act = 0, 0, 0                          # f32: 512-thread kernel, 16 x 32 tiles
     assert h.elvis_conv_stats_tiles(C.byref(d)) == 68 * 60
     d.prologue = 1
