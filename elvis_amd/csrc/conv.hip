@@ -266,6 +266,82 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
 
     // ---- epilogue: lane holds co = cobase + (lane>>4)*4 + r (r=0..3) for pixel col = lane&15
     const int cgrp = (lane >> 4) * 4;
+    if ((p.cout & 3) == 0 && (p.res_pitch & 3) == 0) {
+        // whole 4-channel groups: branch-free (clamped addresses, exec-masked stores).  Per-element
+        // branches around the bias / residual loads cost one serialized memory round trip each.
+        float bv[WCO][4];
+        bool co_ok[WCO];
+#pragma unroll
+        for (int i = 0; i < WCO; ++i) {
+            const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+            co_ok[i] = co < p.cout;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[i][r] = 0.f;
+            if (p.bias) {
+                const float* bp = p.bias + (co_ok[i] ? co : 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[i][r] = bp[r];
+            }
+        }
+        uint2 rv[WCO][WPX];
+        if (p.res) {
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) {
+                const long long m = m0 + (w_px * WPX + j) * 16 + (lane & 15);
+                const long long mc = m < p.M ? m : 0;
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) {
+                    const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+                    const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[i] ? co : 0);
+                    if constexpr (sizeof(T) == 2) rv[i][j] = *reinterpret_cast<const uint2*>(rp);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+            const long long m = m0 + (w_px * WPX + j) * 16 + (lane & 15);
+            const bool m_ok = m < p.M;
+            const long long mc = m_ok ? m : 0;
+#pragma unroll
+            for (int i = 0; i < WCO; ++i) {
+                const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[i][r];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+                } else if (p.act == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
+                if (p.res) {
+                    if constexpr (sizeof(T) == 2) {
+                        const half4 h4 = __builtin_bit_cast(half4, rv[i][j]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)h4[r];
+                    } else {
+                        const float4v f4 = *reinterpret_cast<const float4v*>((const T*)p.res + mc * p.res_pitch + (co_ok[i] ? co : 0));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += f4[r];
+                    }
+                }
+                T* op = (T*)p.out + mc * p.cout_pitch + (co_ok[i] ? co : 0);
+                if (m_ok && co_ok[i]) {
+                    if constexpr (sizeof(T) == 2) {
+                        half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<half4*>(op) = hv;
+                    } else {
+                        *reinterpret_cast<float4v*>(op) = (float4v){v[0], v[1], v[2], v[3]};
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         long long m = m0 + (w_px * WPX + j) * 16 + (lane & 15);
