@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
         bool co_ok[WCO];
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
-            const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+            const int co = co0 + w_co * (16 * WCO) + cgrp * WCO + i * 4;
             co_ok[i] = co < p.cout;
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[i][r] = 0.f;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
                 const long long mc = m < p.M ? m : 0;
 #pragma unroll
                 for (int i = 0; i < WCO; ++i) {
-                    const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+                    const int co = co0 + w_co * (16 * WCO) + cgrp * WCO + i * 4;
                     const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[i] ? co : 0);
                     if constexpr (sizeof(T) == 2) rv[i][j] = *reinterpret_cast<const uint2*>(rp);
                 }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
             const long long mc = m_ok ? m : 0;
 #pragma unroll
             for (int i = 0; i < WCO; ++i) {
-                const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+                const int co = co0 + w_co * (16 * WCO) + cgrp * WCO + i * 4;
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[i][r];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
         if (m >= p.M) continue;
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
-            int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+            int co = co0 + w_co * (16 * WCO) + cgrp * WCO + i * 4;
             if (co >= p.cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             int nv = p.cout - co < 4 ? p.cout - co : 4;
@@ -655,6 +655,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const int lane_off = lds_row_off(lane & 15, lane >> 4);
     const int lq = lane >> 4, lr = lane & 15;
 
+    // The first halo chunk and weight row are requested BEFORE the residual: the two HBM latencies then
+    // overlap instead of adding up (the start-up phase is not hidden by anything but the CU's other
+    // workgroup).
+    constexpr bool EARLY = !G1 && !(NT == 256 && TCO == 64 && TY == 16);   // (the 16-row tile has no registers to spare)
+    if constexpr (EARLY) {
+        halo_load(0, 0, H_PER);
+        if constexpr (WDMA) w_glds(0, 0); else w_load(0);
+    }
     // With no epilogue activation, y = conv + bias + residual: start the accumulators from
     // bias + residual so the residual's HBM latency hides under the start-up instead of sitting
     // on the epilogue's critical path.
@@ -665,11 +673,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const bool vec4 = (p.cout & 3) == 0 && (p.res_pitch & 3) == 0;
     bool co_ok[WCO];
 #pragma unroll
-    for (int i = 0; i < WCO; ++i) co_ok[i] = co0 + (w_co * WCO + i) * 16 + lq * 4 < p.cout;
+    for (int i = 0; i < WCO; ++i) co_ok[i] = co0 + w_co * (16 * WCO) + lq * (4 * WCO) + i * 4 < p.cout;
     auto load_bias = [&](float (&bv)[WCO][4]) {   // vec4 only: 4 unconditional loads per channel group
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
-            const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
+            const int co = co0 + w_co * (16 * WCO) + lq * (4 * WCO) + i * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[i][r] = 0.f;
             if (p.bias) {
@@ -679,6 +687,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             }
         }
     };
+    // wide16: a lane's 4*WCO = 16 channels of a pixel are contiguous (the packed-weight row permutation):
+    // residual loads and output stores move them as two 16-byte accesses on whole 128-byte lines
+    constexpr bool WIDE16 = WCO == 4 && sizeof(T) == 2;
+    const bool wide16 = WIDE16 && vec4 && (p.cout & 15) == 0 && (p.res_pitch & 7) == 0 && (p.cout_pitch & 7) == 0 &&
+                        (((uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0;
     if (fold && vec4) {
         float bv[WCO][4];
         load_bias(bv);
@@ -690,9 +703,24 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
                                             : ((long long)nimg * p.ho + oy) * p.wo + ox;
                 const long long mc = pix_ok ? m : 0;
+                if constexpr (WIDE16) {
+                    if (wide16) {   // the lane's 16 channels of this pixel are 32 contiguous bytes
+                        const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[0] ? co0 + w_co * 64 + lq * 16 : 0);
+                        const uint4 lo = *reinterpret_cast<const uint4*>(rp), hi = *reinterpret_cast<const uint4*>(rp + 8);
+                        const half8 hlo = __builtin_bit_cast(half8, lo), hhi = __builtin_bit_cast(half8, hi);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[0][j][r] = bv[0][r] + (float)hlo[r];
+                            acc[1][j][r] = bv[1][r] + (float)hlo[4 + r];
+                            acc[2][j][r] = bv[2][r] + (float)hhi[r];
+                            acc[3][j][r] = bv[3][r] + (float)hhi[4 + r];
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < WCO; ++i) {
-                    const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
+                    const int co = co0 + w_co * (16 * WCO) + lq * (4 * WCO) + i * 4;
                     const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[i] ? co : 0);
                     if constexpr (sizeof(T) == 2) {
                         half4 rv = *reinterpret_cast<const half4*>(rp);
@@ -722,7 +750,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                                         : ((long long)nimg * p.ho + oy) * p.wo + ox;
 #pragma unroll
             for (int i = 0; i < WCO; ++i) {
-                const int co = co0 + (w_co * WCO + i) * 16 + lq * 4;
+                const int co = co0 + w_co * (16 * WCO) + lq * (4 * WCO) + i * 4;
                 if (!pix_ok || co >= p.cout) continue;
                 const int nv = p.cout - co < 4 ? p.cout - co : 4;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -823,8 +851,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // ---- prologue: halo(0) and weight row 0 into LDS; weight row 1 in flight in registers.
     // The first global loads are issued before the prologue table is built so their latency
     // overlaps it (one workgroup per CU: nothing else hides a workgroup's start-up).
-    halo_load(0, 0, H_PER);
-    if constexpr (WDMA) w_glds(0, 0); else w_load(0);
+    if constexpr (!EARLY && !G1) {
+        halo_load(0, 0, H_PER);
+        if constexpr (WDMA) w_glds(0, 0); else w_load(0);
+    }
     if (PRO) {
         // table entry t = (kc*4 + q)*2*VEC + {0..VEC-1: a, VEC..2VEC-1: b}; channels past the
         // logical count get a = b = 0 (silu(0) = 0 keeps zero padding exact)
@@ -1055,9 +1085,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
                                         : ((long long)nimg * p.ho + oy) * p.wo + ox;
             const long long mc = pix_ok ? m : 0;
+            T wv[WCO][4];
 #pragma unroll
             for (int i = 0; i < WCO; ++i) {
-                const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+                const int co = co0 + w_co * (16 * WCO) + cgrp * WCO + i * 4;
                 const bool ok = pix_ok && co_ok[i];
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if constexpr (ACT) {
@@ -1093,7 +1124,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #ifdef ELVIS_EXP_NOSTORE   /* timing experiment only: stores skipped at run time (never true) */
                 if (p.cout_pitch < 0x7ffffff0) { asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3])); } else
 #endif
-                if (ok) {
+                if (ok && !wide16) {
                     if constexpr (sizeof(T) == 2) {
                         half4 hv = {tv[0], tv[1], tv[2], tv[3]};
                         *reinterpret_cast<half4*>(op) = hv;
@@ -1103,9 +1134,19 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    wv[i][r] = tv[r];
                     const float f = ok ? to_f(tv[r]) : 0.f;   // statistics of the STORED value
                     st[i][r] += f;
                     sq[i][r] = fmaf(f, f, sq[i][r]);
+                }
+            }
+            if constexpr (WIDE16) {
+                if (wide16 && pix_ok && co_ok[0]) {   // 16 contiguous channels: two 16-byte stores
+                    half8 lo = {wv[0][0], wv[0][1], wv[0][2], wv[0][3], wv[1][0], wv[1][1], wv[1][2], wv[1][3]};
+                    half8 hi = {wv[2][0], wv[2][1], wv[2][2], wv[2][3], wv[3][0], wv[3][1], wv[3][2], wv[3][3]};
+                    T* op = (T*)p.out + m * p.cout_pitch + co0 + w_co * 64 + lq * 16;
+                    *reinterpret_cast<half8*>(op) = lo;
+                    *reinterpret_cast<half8*>(op + 8) = hi;
                 }
             }
         }
@@ -1118,7 +1159,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                                     : ((long long)nimg * p.ho + oy) * p.wo + ox;
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
-            const int co = co0 + (w_co * WCO + i) * 16 + cgrp;
+            const int co = co0 + w_co * (16 * WCO) + cgrp * WCO + i * 4;
             if (!pix_ok || co >= p.cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             const int nv = p.cout - co < 4 ? p.cout - co : 4;
@@ -1192,7 +1233,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 // the 16 pixel lanes of a channel group are one DPP row: rotate-and-add, no LDS traffic
                 const float a = row16_sum(st[i][r]), b = row16_sum(sq[i][r]);
                 if (lr == 0) {
-                    int cl = (w_co * WCO + i) * 16 + cgrp + r;
+                    int cl = w_co * (16 * WCO) + cgrp * WCO + i * 4 + r;
                     red[(w_px * TCO + cl) * 2 + 0] = a;
                     red[(w_px * TCO + cl) * 2 + 1] = b;
                 }
@@ -1369,7 +1410,7 @@ template <typename T, int TCO> int launch_halo(const ConvArgs& a, hipStream_t st
 template <typename T> int dispatch(const ConvArgs& a, int id, hipStream_t stream) {
     switch (id) {
         case 0: return launch<T, 4, 4, 2, 2>(a, stream);
-        case 1: return launch<T, 2, 4, 2, 2>(a, stream);
+        case 1: return launch<T, 4, 2, 1, 4>(a, stream);   // 64 cout per wave, like the halo kernels (shared weight permutation)
         case 2: return launch<T, 2, 4, 1, 4>(a, stream);
         default: return launch<T, 1, 4, 1, 4>(a, stream);
     }
@@ -1378,12 +1419,19 @@ template <typename T> int dispatch(const ConvArgs& a, int id, hipStream_t stream
 // ---- weight packing: OIHW f32 -> [tap][kc][co_pad][KC] (T)
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int ctot, int ks,
-                                    int nkc, int co_pad, int KC, long long total) {
+                                    int nkc, int co_pad, int KC, long long total, int wco) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int k = (int)(i % KC);
     long long t = i / KC;
-    int co = (int)(t % co_pad);
+    // Packed row -> output channel.  Within a wave's group of G = 16*wco channels the rows are permuted
+    // so that MFMA fragment i, row 4*lq + r (what lane-quarter lq holds in accumulator register r of
+    // sub-tile i) is channel lq*4*wco + i*4 + r: a lane then owns 4*wco CONTIGUOUS channels of a pixel
+    // and the epilogue moves them with 16-byte accesses on whole cache lines.
+    int row = (int)(t % co_pad);
+    const int G = 16 * wco;
+    const int rho = row % G, fi = rho / 16, q = (rho % 16) / 4, rr = rho % 4;
+    int co = (row / G) * G + q * 4 * wco + fi * 4 + rr;
     t /= co_pad;
     int kc = (int)(t % nkc);
     int tap = (int)(t / nkc);
@@ -1423,12 +1471,13 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
     long long total = (long long)d->ksize * d->ksize * nkc * co_pad * KC;
     int grid = (int)((total + 255) / 256);
     int ctot = d->cin + d->cin2;
+    const int tco_ = choose_tile(d->cout).tco, wco = tco_ >= 64 ? 4 : tco_ / 16;   // 16-row fragments per wave (all kernels agree)
     if (d->dtype == ELVIS_F16)
         hipLaunchKernelGGL(pack_weights_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           (half_t*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total);
+                           (half_t*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total, wco);
     else
         hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           (float*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total);
+                           (float*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total, wco);
     ELVIS_CHECK_LAUNCH("elvis_conv_pack_weights");
     return ELVIS_OK;
 }
@@ -1451,7 +1500,7 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
         snprintf(buf, n, "conv3x3_halo_kernel<%s,%d,%d,%d,%s,%d,%s>", t, c.tco, (halo_two(d) || halo_g1(d)) ? 256 : 512, halo_ty(d),
                  pro ? "true" : "false", d->ksize, d->act ? "true" : "false");
     } else {
-        static const int cfg[4][4] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 4, 1, 4}, {1, 4, 1, 4}};
+        static const int cfg[4][4] = {{4, 4, 2, 2}, {4, 2, 1, 4}, {2, 4, 1, 4}, {1, 4, 1, 4}};
         snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d>", t, cfg[c.id][0], cfg[c.id][1], cfg[c.id][2], cfg[c.id][3]);
     }
     return ELVIS_OK;
