@@ -706,15 +706,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 if constexpr (WIDE16) {
                     if (wide16) {   // the lane's 16 channels of this pixel are 32 contiguous bytes
                         const T* rp = (const T*)p.res + mc * p.res_pitch + (co_ok[0] ? co0 + w_co * 64 + lq * 16 : 0);
-                        const uint4 lo = *reinterpret_cast<const uint4*>(rp), hi = *reinterpret_cast<const uint4*>(rp + 8);
-                        const half8 hlo = __builtin_bit_cast(half8, lo), hhi = __builtin_bit_cast(half8, hi);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[0][j][r] = bv[0][r] + (float)hlo[r];
-                            acc[1][j][r] = bv[1][r] + (float)hlo[4 + r];
-                            acc[2][j][r] = bv[2][r] + (float)hhi[r];
-                            acc[3][j][r] = bv[3][r] + (float)hhi[4 + r];
-                        }
+                        // parked raw in the accumulator registers; converted by res_convert() AFTER the
+                        // prologue table / first-chunk activation, whose work hides this HBM latency
+                        acc[0][j] = __builtin_bit_cast(float4v, *reinterpret_cast<const uint4*>(rp));
+                        acc[2][j] = __builtin_bit_cast(float4v, *reinterpret_cast<const uint4*>(rp + 8));
                         continue;
                     }
                 }
@@ -781,6 +776,25 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         }
     }
 
+    auto res_convert = [&]() {
+        if constexpr (WIDE16) {
+            if (fold && wide16 && p.res) {
+                float bv[WCO][4];
+                load_bias(bv);
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    const half8 hlo = __builtin_bit_cast(half8, acc[0][j]), hhi = __builtin_bit_cast(half8, acc[2][j]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][j][r] = bv[0][r] + (float)hlo[r];
+                        acc[1][j][r] = bv[1][r] + (float)hlo[4 + r];
+                        acc[2][j][r] = bv[2][r] + (float)hhi[r];
+                        acc[3][j][r] = bv[3][r] + (float)hhi[4 + r];
+                    }
+                }
+            }
+        }
+    };
 #ifdef ELVIS_EXP_STAMP
     unsigned long long stamp1 = 0;
 #endif
@@ -814,6 +828,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
         for (int s = 0; s < G1_NST - 1; ++s)
             if (s < nkc) g1_issue(s);
+        res_convert();
         const int pp0 = (w_px * ROWS) * HX + lr;
         int bb[4][2];
 #pragma unroll
@@ -872,6 +887,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         __syncthreads();
     }
     halo_store(0, 0, 0, H_PER);
+    res_convert();
     if constexpr (WDMA) {
         w_glds_wait();
     } else {
