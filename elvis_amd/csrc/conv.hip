@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int chunk = tid + i * NT;
-            if (chunk < A_CHUNKS) ra[i] = *reinterpret_cast<const uint4*>(wsrc + (long long)chunk * 16);
+            if (A_CHUNKS % NT == 0 || chunk < A_CHUNKS) ra[i] = *reinterpret_cast<const uint4*>(wsrc + (long long)chunk * 16);
         }
         // activations: per-pixel gather of one 16-byte channel chunk
         const bool second = kc >= p.nkc1;
@@ -197,14 +197,16 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
         const int kcl = second ? kc - p.nkc1 : kc;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
             int iy = b_oy[i] * p.stride + ky - p.pad;
             int ix = b_ox[i] * p.stride + kx - p.pad;
             int c0 = kcl * KC + b_q[i] * VEC;
-            if (b_ok[i] && iy >= 0 && iy < lh && ix >= 0 && ix < lw && c0 < pitch) {
-                int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-                long long e = (b_nbase[i] + (long long)sy * p.w_in + sx) * pitch + c0;
-                v = *reinterpret_cast<const uint4*>(xsrc + e * (long long)sizeof(T));
+            // branch-free gather: out-of-image / out-of-range chunks read element 0 and are zeroed by a
+            // select (a branch around each load costs a serialized vmcnt(0) round trip per element)
+            const bool ok = b_ok[i] && iy >= 0 && iy < lh && ix >= 0 && ix < lw && c0 < pitch;
+            int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+            long long e = ok ? (b_nbase[i] + (long long)sy * p.w_in + sx) * pitch + c0 : 0;
+            uint4 v = *reinterpret_cast<const uint4*>(xsrc + e * (long long)sizeof(T));
+            {
                 if (p.prologue) {
                     int nimg = (int)(b_nbase[i] / ((long long)p.h * p.w_in));
                     const float* pa = p.pa + (long long)nimg * (p.cin + p.cin2) + (second ? p.cin : 0) + c0;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
                     v = prologue_apply<T>(v, la, lb);
                 }
             }
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
             rb[i] = v;
         }
     };
