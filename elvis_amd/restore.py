@@ -89,7 +89,7 @@ def get_sinsr_upsample_fn(device, *, scale: int = 2, seed: int = DEFAULT_SEED, f
 def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, levels_d: torch.Tensor, block_size: int,
                                  frame_indices: Sequence[int], seed: int = DEFAULT_SEED, swap_rb: bool = True,
                                  noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                                 batch: int = 1) -> torch.Tensor:
+                                 batch: int = 6) -> torch.Tensor:
     """The north-star Downsample path, fully on device: whole frame /4 (INTER_AREA, elvis.py:2565)
     -> ONE SinSR 4x call (README.md:50) -> final-stage paste of elvis.py:2584-2595 at f=1
     (`level == 0 ? decoded frame : SR`).  Frames whose map is all zero skip the network.
