@@ -1310,6 +1310,12 @@ inline bool halo_eligible(const elvis_conv_desc* d) {
 // 512-thread workgroups.  Without the fused prologue: 16 x 32 pixel tile, 64co x 128px per wave
 // (248 VGPRs).  With it: 8 x 32 tile, 64co x 64px per wave, leaving registers for the SiLU math.
 constexpr int HALO_TY = 16, HALO_TY_PRO = 8, HALO_TY_PRO128 = 12, HALO_TX = 32;
+#ifndef ELVIS_G1_TY128
+#define ELVIS_G1_TY128 8
+#endif
+#ifndef ELVIS_G1_TY64
+#define ELVIS_G1_TY64 8
+#endif
 // 256-thread variant, two or three workgroups per CU (f16; 3x3 and sub-pixel 2x2; 128- or 64-channel tile):
 // 6 x 32 pixels x 128 channels (96px x 64co per wave) or 8 x 32 x 64 (64px x 64co per wave)
 // 8 x 32 pixel tiles; the 64-channel tile with the fused prologue uses 16 rows on large images (128 px x
@@ -1341,6 +1347,7 @@ inline bool halo_g1(const elvis_conv_desc* d) {
 }
 inline int halo_ty(const elvis_conv_desc* d) {
     if (halo_two(d)) return halo_ty2(d);
+    if (halo_g1(d)) return choose_tile(d->cout).tco == 128 ? ELVIS_G1_TY128 : ELVIS_G1_TY64;
     if (d->ksize == 3 && d->prologue && choose_tile(d->cout).tco == 128) return HALO_TY_PRO128;
     return (d->prologue || d->ksize == 1) ? HALO_TY_PRO : HALO_TY;
 }
@@ -1388,7 +1395,7 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false,
         if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true, TY2>(a, stream);
     }
     constexpr bool TWO = NT == 256;
-    constexpr int TY = (TWO && KS == 1) ? HALO_TY_PRO : TWO ? TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
+    constexpr int TY = (TWO && KS == 1) ? (TCO == 128 ? ELVIS_G1_TY128 : ELVIS_G1_TY64) : TWO ? TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
     const size_t lds_fixed = (TWO && KS == 1) ? 3 * ((size_t)TY * HALO_TX * 64 + (size_t)TCO * 64)
                            : (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);

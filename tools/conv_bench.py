@@ -17,6 +17,9 @@ SHAPES = {  # name: (cin, cin2, cout, h, w, k, upsample)
     "unet160_320x512": (160, 0, 160, 320, 512, 3, False),
     "unet_cat640_80x128": (320, 320, 320, 80, 128, 3, False),
     "lin192x768": (192, 0, 768, 320, 512, 1, False),
+    "lin192x576": (192, 0, 576, 320, 512, 1, False),
+    "lin768x192": (768, 0, 192, 320, 512, 1, False),
+    "lin192x192": (192, 0, 192, 320, 512, 1, False),
 }
 
 def main():
