@@ -46,7 +46,9 @@ struct ConvArgs {
     int two, tall;        // 256-thread two-workgroups-per-CU variant; its 16-row form
     float* stats;         // [n*tiles_y*tiles_x][cout][2] partial (sum, sumsq) or null
     int tiles_x, tiles_y;
-    int sub, par_a, par_b;   // sub-pixel mode (KS == 2): output pixel (2y+par_a, 2x+par_b)
+    int sub, par_a, par_b;   // 2x2 modes (KS == 2): output pixel (ostr*y + par_a, ostr*x + par_b)
+    int ostr, pad2y, pad2x;  // sub-pixel: ostr 2, pad 1 - par; space-to-depth stride-2 form: ostr 1, pad 0
+    int s2d, istr, nkc_c, wfull;   // s2d: K chunk kc = phase (kc / nkc_c) of the full-res input (row stride wfull), istr = 2
 };
 
 template <typename T> struct Frag;
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const int w_co = wave / NW_PX, w_px = wave % NW_PX;
     const int lh = p.upsample ? p.h * 2 : p.h, lw = p.upsample ? p.w_in * 2 : p.w_in;
 
-    const int pad_y = KS == 2 ? 1 - p.par_a : KS / 2, pad_x = KS == 2 ? 1 - p.par_b : KS / 2;
+    const int pad_y = KS == 2 ? p.pad2y : KS / 2, pad_x = KS == 2 ? p.pad2x : KS / 2;
     // ---- halo staging plan: chunk = tid + NT*i -> (halo pixel, 16-byte channel slice q = tid&3).
     // Branch-free: out-of-image / out-of-range chunks load pixel 0 and are zeroed by a select, so
     // the compiler can keep counted (not vmcnt(0)) waits on the prefetch pipeline.
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         int gy = oy0 + hy - pad_y, gx = ox0 + hx - pad_x;
         bool ok = chunk < HCH && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
         int sy = p.upsample ? (gy >> 1) : gy, sx = p.upsample ? (gx >> 1) : gx;
-        h_src[i] = ok ? (nimg * p.h + sy) * p.w_in + sx : 0;
+        h_src[i] = ok ? ((nimg * p.h + sy) * p.istr * p.w_in + sx) * p.istr : 0;   // istr 2: pixel (2sy, 2sx) of the full-res input
         h_ok |= (ok ? 1u : 0u) << i;
     }
     const int q4 = tid & 3;   // NT is a multiple of 4: every chunk of this thread has the same q
@@ -520,20 +522,32 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         wl_off[i] = lds_row_off(chunk >> 2, chunk & 3);
     }
 
+    // channel offset (and, in the space-to-depth form, the phase's pixel offset) of K chunk kc
+    auto chunk_c0 = [&](int kc, int& pixoff) -> int {
+        pixoff = 0;
+        if (KS == 2 && p.s2d) {
+            const int ph = kc / p.nkc_c;
+            pixoff = (ph >> 1) * p.wfull + (ph & 1);
+            return (kc - ph * p.nkc_c) * KC + q4 * VEC;
+        }
+        return (kc >= p.nkc1 ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+    };
     auto halo_load = [&](int kc, int i0, int i1) {
         const bool second = kc >= p.nkc1;
         const char* xsrc = (const char*)(second ? p.x2 : p.x);
         const int pitch = second ? p.cin2_pitch : p.cin_pitch;
-        const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+        int pixoff;
+        const int c0 = chunk_c0(kc, pixoff);
         const int c0c = c0 < pitch ? c0 : 0;
 #pragma unroll
         for (int i = i0; i < i1; ++i)
-            hreg[i] = *reinterpret_cast<const uint4*>(xsrc + ((long long)h_src[i] * pitch + c0c) * (long long)sizeof(T));
+            hreg[i] = *reinterpret_cast<const uint4*>(xsrc + ((long long)(h_src[i] + pixoff) * pitch + c0c) * (long long)sizeof(T));
     };
     auto halo_store = [&](int kc, int buf, int i0, int i1) {
         const bool second = kc >= p.nkc1;
         const int pitch = second ? p.cin2_pitch : p.cin_pitch;
-        const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+        int pixoff_;
+        const int c0 = chunk_c0(kc, pixoff_);
         const bool ch_ok = c0 < pitch;
         char* dst = halo + buf * HALO_BYTES;
         float la[VEC], lb[VEC];
@@ -577,7 +591,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     auto halo_write = [&](int kc, int buf, int slot) {
         const bool second = kc >= p.nkc1;
         const int pitch = second ? p.cin2_pitch : p.cin_pitch;
-        const int c0 = (second ? kc - p.nkc1 : kc) * KC + q4 * VEC;
+        int pixoff_;
+        const int c0 = chunk_c0(kc, pixoff_);
         const bool keep = c0 < pitch && ((h_ok >> slot) & 1u);
         uint4 v = hreg[slot];
         v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             for (int j = 0; j < WPX; ++j) {
                 const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
                 const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
-                const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+                const long long m = KS == 2 ? ((long long)nimg * p.ho + p.ostr * oy + p.par_a) * p.wo + p.ostr * ox + p.par_b
                                             : ((long long)nimg * p.ho + oy) * p.wo + ox;
                 const long long mc = pix_ok ? m : 0;
                 if constexpr (WIDE16) {
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         for (int j = 0; j < WPX; ++j) {
             const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
             const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
-            const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+            const long long m = KS == 2 ? ((long long)nimg * p.ho + p.ostr * oy + p.par_a) * p.wo + p.ostr * ox + p.par_b
                                         : ((long long)nimg * p.ho + oy) * p.wo + ox;
 #pragma unroll
             for (int i = 0; i < WCO; ++i) {
@@ -1101,7 +1116,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         for (int j = 0; j < WPX; ++j) {
             const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
             const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
-            const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+            const long long m = KS == 2 ? ((long long)nimg * p.ho + p.ostr * oy + p.par_a) * p.wo + p.ostr * ox + p.par_b
                                         : ((long long)nimg * p.ho + oy) * p.wo + ox;
             const long long mc = pix_ok ? m : 0;
             T wv[WCO][4];
@@ -1174,7 +1189,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     for (int j = 0; j < WPX; ++j) {
         const int oy = oy0 + w_px * ROWS + (j >> 1), ox = ox0 + (j & 1) * 16 + lr;
         const bool pix_ok = KS == 2 ? (oy < p.h && ox < p.w_in) : (oy < p.ho && ox < p.wo);
-        const long long m = KS == 2 ? ((long long)nimg * p.ho + 2 * oy + p.par_a) * p.wo + 2 * ox + p.par_b
+        const long long m = KS == 2 ? ((long long)nimg * p.ho + p.ostr * oy + p.par_a) * p.wo + p.ostr * ox + p.par_b
                                     : ((long long)nimg * p.ho + oy) * p.wo + ox;
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
@@ -1357,13 +1372,18 @@ int validate(const elvis_conv_desc* d) {
     ELVIS_REQUIRE(d->dtype == ELVIS_F32 || d->dtype == ELVIS_F16, "conv: bad dtype %d", d->dtype);
     ELVIS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->ho > 0 && d->wo > 0,
                   "conv: bad shape n=%d h=%d w=%d cin=%d cout=%d ho=%d wo=%d", d->n, d->h, d->w, d->cin, d->cout, d->ho, d->wo);
-    ELVIS_REQUIRE(d->ksize == 1 || d->ksize == 3 || (d->ksize == 2 && d->subpixel >= 1 && d->subpixel <= 4),
-                  "conv: ksize must be 1 or 3, or 2 with subpixel = 1 + parity (got ksize %d, subpixel %d)", d->ksize, d->subpixel);
-    if (d->ksize == 2)
+    ELVIS_REQUIRE(d->ksize == 1 || d->ksize == 3 || (d->ksize == 2 && d->subpixel >= 1 && d->subpixel <= 5),
+                  "conv: ksize must be 1 or 3, or 2 with subpixel = 1 + parity / 5 (got ksize %d, subpixel %d)", d->ksize, d->subpixel);
+    const bool s2d = d->ksize == 2 && d->subpixel == ELVIS_CONV_S2D;
+    if (d->ksize == 2 && !s2d)
         ELVIS_REQUIRE(d->stride == 1 && !d->upsample && !d->prologue && d->ho == 2 * d->h && d->wo == 2 * d->w,
                       "conv: a sub-pixel parity conv maps h x w to 2h x 2w, stride 1, no prologue");
+    if (s2d)
+        ELVIS_REQUIRE(!d->upsample && !d->prologue && d->cin2 == 0 && d->h == 2 * d->ho && d->w == 2 * d->wo && d->cin % 128 == 0 &&
+                          d->dtype == ELVIS_F16 && d->cout >= 64,
+                      "conv: the space-to-depth stride-2 form maps 2ho x 2wo to ho x wo, f16, cin = 4 x (a multiple of 32), cout >= 64");
     ELVIS_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2");
-    ELVIS_REQUIRE(d->cin_pitch >= d->cin && d->cin_pitch % 8 == 0, "conv: cin_pitch %d must be >= cin %d and a multiple of 8", d->cin_pitch, d->cin);
+    ELVIS_REQUIRE(d->cin_pitch >= (s2d ? d->cin / 4 : d->cin) && d->cin_pitch % 8 == 0, "conv: cin_pitch %d must be >= cin %d and a multiple of 8", d->cin_pitch, d->cin);
     ELVIS_REQUIRE(d->cout_pitch >= d->cout && d->cout_pitch % 4 == 0, "conv: cout_pitch %d invalid for cout %d", d->cout_pitch, d->cout);
     int kc = kc_elems(d->dtype);
     if (d->cin2 > 0) {
@@ -1511,7 +1531,7 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
 extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     if (!d || !halo_eligible(d)) return 0;
     int ty = halo_ty(d);
-    if (d->ksize == 2) return d->n * ((d->h + ty - 1) / ty) * ((d->w + HALO_TX - 1) / HALO_TX);   // per parity launch
+    if (d->ksize == 2 && d->subpixel != ELVIS_CONV_S2D) return d->n * ((d->h + ty - 1) / ty) * ((d->w + HALO_TX - 1) / HALO_TX);   // per parity launch
     return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
 }
 
@@ -1556,14 +1576,27 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.n_co_tiles = a.co_pad / t.tco;
     a.n_px_tiles = (a.M + t.tpx - 1) / t.tpx;
     a.stats = stats;
+    const bool s2d = d->ksize == 2 && d->subpixel == ELVIS_CONV_S2D;
+    const bool subpix = d->ksize == 2 && !s2d;
     a.sub = d->ksize == 2;
-    a.par_a = d->ksize == 2 ? (d->subpixel - 1) >> 1 : 0;
-    a.par_b = d->ksize == 2 ? (d->subpixel - 1) & 1 : 0;
-    a.tiles_x = ((d->ksize == 2 ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
+    a.par_a = subpix ? (d->subpixel - 1) >> 1 : 0;
+    a.par_b = subpix ? (d->subpixel - 1) & 1 : 0;
+    a.ostr = subpix ? 2 : 1;
+    a.pad2y = subpix ? 1 - a.par_a : 0;
+    a.pad2x = subpix ? 1 - a.par_b : 0;
+    a.s2d = s2d ? 1 : 0;
+    a.istr = s2d ? 2 : 1;
+    a.nkc_c = s2d ? d->cin / 4 / 32 : 0x3fffffff;
+    a.wfull = d->w;
+    if (s2d) {   // the kernel sees the phase image: ho x wo pixels of 4C channels
+        a.h = d->ho;
+        a.w_in = d->wo;
+    }
+    a.tiles_x = ((subpix ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
     const int tyv = halo_ty(d);
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;
-    a.tiles_y = ((d->ksize == 2 ? d->h : d->ho) + tyv - 1) / tyv;
+    a.tiles_y = ((subpix ? d->h : d->ho) + tyv - 1) / tyv;
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
         hipStream_t st = (hipStream_t)stream;

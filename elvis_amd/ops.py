@@ -306,6 +306,66 @@ class PackedUpConv:
         return out
 
 
+class PackedDownConv:
+    """`conv3x3(pad(x, (0,1,0,1)), stride=2)` - the autoencoder's Downsample - in
+    space-to-depth form: the four (row, column) phases of the full-res input are read as 4C channels of
+    an ho x wo image and a 2x2 conv with the re-indexed 3x3 taps runs on the halo-tile kernel
+    (W[2ry+py][2rx+px] at channel (2py+px)*C + c, tap (ry, rx); 7 of the 16 phase/tap blocks are
+    zero).  Same result as the strided conv in real arithmetic; 1.78x the MFMA work of the direct form,
+    at ~3.5x its rate on the generic strided kernel.  f16, C % 32 == 0, cout >= 64."""
+
+    S2D = 5   # ELVIS_CONV_S2D
+
+    def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int):
+        cout, ctot, kh, kw = weight_oihw.shape
+        assert kh == 3 and kw == 3 and ctot == cin and cin % 32 == 0 and dtype == torch.float16
+        self.cin, self.cout, self.device = cin, cout, device
+        w = weight_oihw.float()
+        w4 = torch.zeros(cout, 4 * cin, 2, 2)
+        for dy in range(3):
+            for dx in range(3):
+                ry, py, rx, px = dy // 2, dy % 2, dx // 2, dx % 2
+                ph = 2 * py + px
+                w4[:, ph * cin:(ph + 1) * cin, ry, rx] = w[:, :, dy, dx]
+        d = self._desc(1, 2, 2, pitch_for(cin), pitch_for(cout))
+        nbytes = lib().elvis_conv_packed_weight_bytes(C.byref(d))
+        w_dev = w4.to(device=device).contiguous()
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(lib().elvis_conv_pack_weights(C.byref(d), ptr(w_dev), ptr(self.packed), _s(self.packed)), device)
+        torch.cuda.current_stream(device).synchronize()
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+
+    def _desc(self, n, h, w, cin_pitch, cout_pitch):
+        d = ConvDesc()
+        d.dtype = L.F16
+        d.n, d.h, d.w, d.ho, d.wo = n, h, w, h // 2, w // 2
+        d.cin, d.cin_pitch = 4 * self.cin, cin_pitch
+        d.cout, d.cout_pitch = self.cout, cout_pitch
+        d.ksize, d.stride, d.subpixel = 2, 1, self.S2D
+        return d
+
+    def __call__(self, x: Act, want_stats: bool = False) -> Act:
+        if x.c != self.cin or x.h % 2 or x.w % 2:
+            raise ValueError(f"downsample conv: expected {self.cin} channels and even H, W; got {x.c}, {x.h}x{x.w}")
+        out = new_act(x.n, x.h // 2, x.w // 2, self.cout, x.t.dtype, x.t.device)
+        d = self._desc(x.n, x.h, x.w, x.pitch, out.pitch)
+        tiles = lib().elvis_conv_stats_tiles(C.byref(d))
+        stats = torch.empty((tiles, self.cout, 2), dtype=torch.float32, device=x.t.device) if want_stats and tiles > 0 else None
+        prof = CONV_PROFILER
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(lib().elvis_conv2d(C.byref(d), ptr(x.t), 0, ptr(self.packed), ptr(self.bias), 0, 0, 0, 0, ptr(out.t),
+                                 ptr(stats), _s(x.t)), x.t.device)
+        if prof is not None:
+            e1.record()
+            prof.append((conv_kernel_name(d), 2.0 * 9 * self.cin * self.cout * x.n * out.h * out.w, e0, e1))   # algorithmic FLOPs of the 3x3/s2 conv
+            if CONV_SHAPES is not None:
+                CONV_SHAPES.append((x.n, x.h, x.w, self.cin, self.cout, 3, 2, False, False))
+        out.stats = stats
+        return out
+
+
 def groupnorm_affine(xs, gamma, beta, groups, eps, scale=None, shift=None):
     """GroupNorm statistics over the (virtual) channel concat of `xs` -> per-(n,c) affine (pa, pb)
     such that GN(x)*(1+scale)+shift == x*pa + pb."""

@@ -31,6 +31,25 @@ def _conv(sd, p, dtype, device, cin, cin2=0) -> PackedConv:
     return PackedConv(sd[p + ".weight"], sd[p + ".bias"], dtype, device, cin, cin2)
 
 
+class _DownConv:
+    """The autoencoder's Downsample: pad (0,1,0,1) + 3x3 conv, stride 2.  f16 with whole 32-channel
+    chunks and even sizes: the space-to-depth form on the halo-tile kernel (ops.PackedDownConv, with
+    fused GroupNorm statistics); otherwise (fp32 mode, ELVIS_NO_S2D=1, odd sizes) the generic strided
+    kernel - same result to rounding."""
+
+    def __init__(self, sd, p, dtype, device, cin):
+        import os
+        self.direct = _conv(sd, p, dtype, device, cin)
+        self.s2d = None
+        if dtype == torch.float16 and cin % 32 == 0 and sd[p + ".weight"].shape[0] >= 64 and not os.environ.get("ELVIS_NO_S2D"):
+            self.s2d = ops.PackedDownConv(sd[p + ".weight"], sd[p + ".bias"], dtype, device, cin)
+
+    def __call__(self, x: Act, want_stats=False) -> Act:
+        if self.s2d is not None and x.h % 2 == 0 and x.w % 2 == 0:
+            return self.s2d(x, want_stats=want_stats)
+        return self.direct(x, stride=2, pad=0, ho=x.h // 2, wo=x.w // 2)
+
+
 class _UpConv:
     """nearest-2x upsample + 3x3 conv: sub-pixel 2x2 decomposition (2.25x fewer FLOPs) or the
     fused-upsample 3x3 kernel (ELVIS_NO_SUBPIXEL=1 / subpixel=False), same results to rounding."""
@@ -215,7 +234,7 @@ class SinSRModel:
             for b in range(nrb):
                 blocks.append(rb(f"ae.encoder.down.{lvl}.block.{b}", cin, ch * m))
                 cin = ch * m
-            ds = _conv(sd, f"ae.encoder.down.{lvl}.downsample.conv", dt, dev, cin) if lvl != len(mults) - 1 else None
+            ds = _DownConv(sd, f"ae.encoder.down.{lvl}.downsample.conv", dt, dev, cin) if lvl != len(mults) - 1 else None
             self.e_down.append((blocks, ds))
         self.e_mid = [rb("ae.encoder.mid.block_1", cin, cin), rb("ae.encoder.mid.block_2", cin, cin)]
         self.e_norm_out = _GN(sd, "ae.encoder.norm_out", dev)
@@ -275,7 +294,7 @@ class SinSRModel:
             for b in blocks:
                 h = b(h, fuse_gn=self.fuse_gn)
             if ds is not None:
-                h = ds(h, stride=2, pad=0, ho=h.h // 2, wo=h.w // 2)
+                h = ds(h, want_stats=self.fuse_gn)
         for b in self.e_mid:
             h = b(h, fuse_gn=self.fuse_gn)
         h = self._gn_silu_conv(h, self.e_norm_out, self.e_conv_out, 1e-6)

@@ -128,10 +128,17 @@ typedef struct elvis_conv_desc {
     int ho, wo;         /* output spatial size                                                 */
     int act;            /* epilogue activation: 0 none, 1 GELU(erf), 2 SiLU, 3 ReLU            */
     int prologue;       /* 0 none, 1: x <- silu(x*pa[n,c]+pb[n,c]) on load (fused GroupNorm)   */
-    int subpixel;       /* ksize == 2 only: 1 + parity (2a+b) of the sub-pixel decomposition of
+    int subpixel;       /* ksize == 2 only.  1..4: 1 + parity (2a+b) of the sub-pixel decomposition of
                            "nearest-2x upsample + 3x3 conv": this launch writes output pixels
-                           (2y+a, 2x+b) of the 2h x 2w output from 2x2 pre-summed taps          */
+                           (2y+a, 2x+b) of the 2h x 2w output from 2x2 pre-summed taps.
+                           ELVIS_CONV_S2D (5): the space-to-depth form of "pad (0,1,0,1) + 3x3 conv,
+                           stride 2" (the autoencoder's Downsample): x is the full-res h x w tensor of
+                           C = cin/4 channels, the kernel reads its four (row, column) phases as
+                           4C channels of an ho x wo image (ho = h/2, wo = w/2) and applies a 2x2
+                           conv whose OIHW weights [cout][4C][2][2] hold W[2ry+py][2rx+px] at input
+                           channel (2py+px)*C + c, tap (ry, rx) (zero where 2r+p > 2).  f16, C % 32 == 0 */
 } elvis_conv_desc;
+#define ELVIS_CONV_S2D 5
 
 /* Number of bytes of the packed weight buffer for a conv (depends on cin/cin2/cout/ksize/dtype). */
 size_t elvis_conv_packed_weight_bytes(const elvis_conv_desc* d);

@@ -347,3 +347,32 @@ def test_u8_float_roundtrip(gpu_device):
     assert float(a.t[..., 3:].abs().max()) == 0.0
     back, f32 = ops.float_to_u8(a, 0.5, 0.5, mode=0, swap_rb=True, want_f32=True)
     assert torch.equal(back.cpu(), img.cpu())
+
+
+@pytest.mark.parametrize("cfg", [(128, 128, 20, 36), (64, 192, 18, 70), (256, 256, 34, 64)])
+def test_downsample_conv_space_to_depth(gpu_device, cfg):
+    """pad (0,1,0,1) + 3x3 / stride 2 in space-to-depth form (2x2 conv over the four input phases) == the
+    direct strided conv; fused GroupNorm statistics == sums of the stored tensor."""
+    from elvis_amd import ops
+    cin, cout, h, w = cfg
+    g = torch.Generator().manual_seed(21)
+    n = 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = ops.PackedDownConv(wt, b, torch.float16, gpu_device, cin)
+    y = conv(_act(x, torch.float16, gpu_device), want_stats=True)
+    ref = F.conv2d(F.pad(x.half().float(), (0, 1, 0, 1)), wt.half().float(), b, stride=2)
+    got = _nchw(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL[torch.float16]
+    assert y.stats is not None
+    sums = torch.zeros((n, cout, 2), dtype=torch.float64, device=gpu_device)
+    from elvis_amd._lib import lib, check, ptr
+    check(lib().elvis_gn_partials_to_sums(ptr(y.stats), y.stats.shape[0] // n, n, cout, ptr(sums), cout, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+    assert torch.allclose(sums.cpu()[:, :, 0], got.double().sum((2, 3)), rtol=1e-5, atol=1e-2)
+    # and against the generic strided kernel on the same packed-from-OIHW weights
+    direct = ops.PackedConv(wt, b, torch.float16, gpu_device, cin)
+    y0 = direct(_act(x, torch.float16, gpu_device), stride=2, pad=0, ho=h // 2, wo=w // 2)
+    assert (_nchw(y0) - got).abs().max().item() < TOL[torch.float16]
