@@ -93,6 +93,35 @@ __global__ __launch_bounds__(256) void gn_partials_reduce_kernel(const float* __
     }
 }
 
+// Same reduction, four adjacent channels per workgroup: every thread reads 32 contiguous bytes per tile
+// (whole sectors instead of 8 of every 32 bytes).  Per channel the accumulation order is exactly that of
+// gn_partials_reduce_kernel, so the sums are bit-identical.  grid = (c/4, n), c % 4 == 0.
+__global__ __launch_bounds__(256) void gn_partials_reduce4_kernel(const float* __restrict__ partials,
+                                                                  int tiles_per_image, int c,
+                                                                  double* __restrict__ sums, int ctot, int coff) {
+    __shared__ double red[8][256];
+    const int ch = blockIdx.x * 4, n = blockIdx.y, tid = threadIdx.x;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* base = partials + ((long long)n * tiles_per_image * c + ch) * 2;
+    for (int t = tid; t < tiles_per_image; t += 256) {
+        const float4* p4 = reinterpret_cast<const float4*>(base + (long long)t * c * 2);
+        const float4 u = p4[0], v = p4[1];
+        acc[0] += (double)u.x; acc[1] += (double)u.y; acc[2] += (double)u.z; acc[3] += (double)u.w;
+        acc[4] += (double)v.x; acc[5] += (double)v.y; acc[6] += (double)v.z; acc[7] += (double)v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[k][tid] += red[k][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid < 8) sums[((long long)n * ctot + coff + ch) * 2 + tid] = red[tid][0];
+}
+
 __global__ void gn_affine_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ scale,
                                  const float* __restrict__ shift, float* __restrict__ pa, float* __restrict__ pb,
@@ -250,8 +279,12 @@ extern "C" int elvis_gn_partials_to_sums(const float* partials, int tiles_per_im
                                          int sums_ctot, int sums_coff, elvis_stream_t stream) {
     ELVIS_REQUIRE(partials && sums && tiles_per_image > 0 && n > 0 && c > 0, "elvis_gn_partials_to_sums: bad argument");
     ELVIS_REQUIRE(sums_coff >= 0 && sums_coff + c <= sums_ctot, "elvis_gn_partials_to_sums: channel slice outside buffer");
-    hipLaunchKernelGGL(gn_partials_reduce_kernel, dim3(c, n), dim3(256), 0, (hipStream_t)stream, partials,
-                       tiles_per_image, c, sums, sums_ctot, sums_coff);
+    if (c % 4 == 0 && ((uintptr_t)partials & 15) == 0)
+        hipLaunchKernelGGL(gn_partials_reduce4_kernel, dim3(c / 4, n), dim3(256), 0, (hipStream_t)stream, partials,
+                           tiles_per_image, c, sums, sums_ctot, sums_coff);
+    else
+        hipLaunchKernelGGL(gn_partials_reduce_kernel, dim3(c, n), dim3(256), 0, (hipStream_t)stream, partials,
+                           tiles_per_image, c, sums, sums_ctot, sums_coff);
     ELVIS_CHECK_LAUNCH("elvis_gn_partials_to_sums");
     return ELVIS_OK;
 }
