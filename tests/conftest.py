@@ -24,3 +24,10 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libelvis_amd.so, built in-tree with hipcc if this checkout has not been built yet (no GPU needed)."""
+    from elvis_amd import _build
+    return _build.build(verbose=False)

@@ -18,7 +18,7 @@ def _header_decls():
     return decls
 
 
-def test_header_symbols_exported_and_bound():
+def test_header_symbols_exported_and_bound(built_lib):
     decls = _header_decls()
     assert len(decls) >= 20
     handle = _lib.lib()
@@ -31,7 +31,7 @@ def test_header_symbols_exported_and_bound():
     assert handle.elvis_abi_version() == 1
 
 
-def test_argument_validation_without_gpu():
+def test_argument_validation_without_gpu(built_lib):
     """Entry points validate shapes before touching the device: ELVIS_E_INVALID (-1) + message."""
     import ctypes as C
     h = _lib.lib()
