@@ -72,6 +72,12 @@ __device__ __forceinline__ int lds_row_off(int row, int q) {
     return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
+#ifndef ELVIS_G1_NST128
+#define ELVIS_G1_NST128 3
+#endif
+#ifndef ELVIS_G1_NST64
+#define ELVIS_G1_NST64 2   /* ring stages of the 1x1 GEMM path with a 64-channel tile */
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // weights of the 256-thread kernels: LDS-DMA (no staging registers) or register staging
     constexpr bool WDMA = TWO && ELVIS_TWO_WDMA;
     constexpr bool G1 = TWO && KS == 1;
-    constexpr int G1_NST = 3;
+    constexpr int G1_NST = TCO == 64 ? ELVIS_G1_NST64 : ELVIS_G1_NST128;
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
     constexpr int HALO_BYTES = HP * 64;
@@ -1416,7 +1422,7 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false,
     }
     constexpr bool TWO = NT == 256;
     constexpr int TY = (TWO && KS == 1) ? (TCO == 128 ? ELVIS_G1_TY128 : ELVIS_G1_TY64) : TWO ? TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
-    const size_t lds_fixed = (TWO && KS == 1) ? 3 * ((size_t)TY * HALO_TX * 64 + (size_t)TCO * 64)
+    const size_t lds_fixed = (TWO && KS == 1) ? (TCO == 64 ? ELVIS_G1_NST64 : ELVIS_G1_NST128) * ((size_t)TY * HALO_TX * 64 + (size_t)TCO * 64)
                            : (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
