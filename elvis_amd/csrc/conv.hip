@@ -682,7 +682,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // The first halo chunk and weight row are requested BEFORE the residual: the two HBM latencies then
     // overlap instead of adding up (the start-up phase is not hidden by anything but the CU's other
     // workgroup).
-    constexpr bool EARLY = !G1 && !(NT == 256 && TCO == 64 && TY == 16);   // (the 16-row tile has no registers to spare)
+    constexpr bool EARLY = !G1 && !(NT == 256 && TCO == 64 && TY == 16) && !(NT == 256 && TCO == 128 && KS == 2);   // (these two have no registers to spare)
     if constexpr (EARLY) {
         halo_load(0, 0, H_PER);
         if constexpr (WDMA) w_glds(0, 0); else w_load(0);
