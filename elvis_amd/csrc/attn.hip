@@ -115,15 +115,19 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const T* __restri
 constexpr int P_PITCH = NTOK + 8;   // halfs; 144-byte rows keep ds_read_b128 16-byte aligned
 constexpr int V_PITCH = NTOK + 8;   // halfs; V is kept TRANSPOSED ([d][key], 144-byte rows) so a B fragment is one ds_read_b128
 
-__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t* __restrict__ qkv,
+#ifndef ELVIS_ATT_WAVES
+#define ELVIS_ATT_WAVES 2   /* waves per workgroup (= heads in flight per window): 2 -> 30 KB of LDS, five workgroups per CU (-26 % vs 4) */
+#endif
+constexpr int ATT_NW = ELVIS_ATT_WAVES;
+__global__ __launch_bounds__(64 * ATT_NW) void window_attention_mfma_kernel(const half_t* __restrict__ qkv,
                                                                     half_t* __restrict__ out, int h, int w,
                                                                     int heads, int shift, int qkv_pitch,
                                                                     int out_pitch,
                                                                     const float* __restrict__ bias_table,
                                                                     float scale) {
-    __shared__ __attribute__((aligned(16))) half_t sP[4][NTOK * P_PITCH];
-    __shared__ __attribute__((aligned(16))) half_t sV[4][HD * V_PITCH];
-    __shared__ float sBias[4][(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ __attribute__((aligned(16))) half_t sP[ATT_NW][NTOK * P_PITCH];
+    __shared__ __attribute__((aligned(16))) half_t sV[ATT_NW][HD * V_PITCH];
+    __shared__ float sBias[ATT_NW][(2 * WS - 1) * (2 * WS - 1)];
     __shared__ int s_pos[NTOK];
     __shared__ int s_region[NTOK];
     const int E = heads * HD;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const half_t
     half_t* myV = sV[wave];
     float* myB = sBias[wave];
 
-    for (int head = wave; head < heads; head += 4) {
+    for (int head = wave; head < heads; head += ATT_NW) {
         // relative-position bias column of this head -> LDS
         for (int t = lane; t < (2 * WS - 1) * (2 * WS - 1); t += 64) myB[t] = bias_table[t * heads + head];
         // V tile (64 keys x 32 dims) -> LDS, one 16-byte chunk per lane-iteration
@@ -277,7 +281,7 @@ extern "C" int elvis_window_attention(const void* qkv, void* out, int dtype, int
     if (dtype == ELVIS_F16 && !getenv("ELVIS_ATTN_VALU")) {
         // MFMA path: one workgroup per window, waves loop over heads
         long long wblocks = (long long)n * (h / ws) * (w / ws);
-        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)wblocks), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)wblocks), dim3(64 * ATT_NW), 0, (hipStream_t)stream,
                            (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);
     } else if (dtype == ELVIS_F16)
         hipLaunchKernelGGL(window_attention_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
