@@ -208,11 +208,11 @@ def main():
         # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs of this same workload, tools/pmc_traffic.py); null if none is on file
         traffic = traffic_src = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_j_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k_hbm_traffic.json")
         if os.path.exists(tpath) and args.batch == 15 and (args.height, args.width) == (1080, 1920):
             rec = json.load(open(tpath))["kernels"].get(name)
             if rec:
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_j_hbm_traffic.json (PMC, separate passes)"
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_k_hbm_traffic.json (PMC, separate passes)"
         roof = {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src, "launches": cnt,
