@@ -218,6 +218,29 @@ __global__ __launch_bounds__(256) void crop_copy_kernel(const T* __restrict__ x,
     }
 }
 
+// dtype conversion of a pitched NHWC tensor (mixed-precision section boundaries): 8 elements per thread
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_act_kernel(const TS* __restrict__ x, TD* __restrict__ y, long long total8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+        TS v[8];
+        TD o[8];
+        if constexpr (sizeof(TS) == 2) {
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(x + i * 8);
+        } else {
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(x + i * 8);
+            *reinterpret_cast<uint4*>(v + 4) = *reinterpret_cast<const uint4*>(x + i * 8 + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = from_f<TD>(to_f(v[k]));
+        if constexpr (sizeof(TD) == 2) {
+            *reinterpret_cast<uint4*>(y + i * 8) = *reinterpret_cast<uint4*>(o);
+        } else {
+            *reinterpret_cast<uint4*>(y + i * 8) = *reinterpret_cast<uint4*>(o);
+            *reinterpret_cast<uint4*>(y + i * 8 + 4) = *reinterpret_cast<uint4*>(o + 4);
+        }
+    }
+}
+
 inline int grid_for(long long total) {
     long long g = (total + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
@@ -335,5 +358,22 @@ extern "C" int elvis_crop_copy(const void* x, void* y, int dtype, int n, int h_i
     else
         ELVIS_REQUIRE(false, "elvis_crop_copy: bad dtype");
     ELVIS_CHECK_LAUNCH("elvis_crop_copy");
+    return ELVIS_OK;
+}
+
+extern "C" int elvis_convert_act(const void* x, int src_dtype, void* y, int dst_dtype, long long pixels, int pitch,
+                                 elvis_stream_t stream) {
+    ELVIS_REQUIRE(x && y && pixels > 0 && pitch > 0 && pitch % 8 == 0, "elvis_convert_act: bad argument");
+    ELVIS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "elvis_convert_act: pointers must be 16-byte aligned");
+    const long long total8 = pixels * (pitch / 8);
+    if (src_dtype == ELVIS_F16 && dst_dtype == ELVIS_F32)
+        hipLaunchKernelGGL((convert_act_kernel<half_t, float>), dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream,
+                           (const half_t*)x, (float*)y, total8);
+    else if (src_dtype == ELVIS_F32 && dst_dtype == ELVIS_F16)
+        hipLaunchKernelGGL((convert_act_kernel<float, half_t>), dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (half_t*)y, total8);
+    else
+        ELVIS_REQUIRE(false, "elvis_convert_act: unsupported conversion %d -> %d", src_dtype, dst_dtype);
+    ELVIS_CHECK_LAUNCH("elvis_convert_act");
     return ELVIS_OK;
 }

@@ -189,6 +189,9 @@ class PackedConv:
                  want_stats: bool = False) -> Act:
         if x.c != self.cin or (x2.c if x2 is not None else 0) != self.cin2:
             raise ValueError(f"conv: expected inputs with {self.cin}+{self.cin2} channels, got {x.c}+{x2.c if x2 else 0}")
+        for t in (x, x2, residual):
+            if t is not None and t.t.dtype != self.dtype:
+                raise ValueError(f"conv: weights are packed for {self.dtype}, got a {t.t.dtype} tensor")
         d = ConvDesc()
         d.dtype = x.dtype_code
         d.n, d.h, d.w = x.n, x.h, x.w
@@ -271,6 +274,8 @@ class PackedUpConv:
                 self.par.append(PackedConv(w2, bias, dtype, device, cin))
 
     def __call__(self, x: Act, want_stats: bool = False, act: int = 0) -> Act:
+        if x.t.dtype != self.par[0].dtype:
+            raise ValueError(f"conv: weights are packed for {self.par[0].dtype}, got a {x.t.dtype} tensor")
         n, h, w = x.n, x.h, x.w
         out = new_act(n, 2 * h, 2 * w, self.cout, x.t.dtype, x.t.device)
         stats = None
@@ -345,8 +350,8 @@ class PackedDownConv:
         return d
 
     def __call__(self, x: Act, want_stats: bool = False) -> Act:
-        if x.c != self.cin or x.h % 2 or x.w % 2:
-            raise ValueError(f"downsample conv: expected {self.cin} channels and even H, W; got {x.c}, {x.h}x{x.w}")
+        if x.c != self.cin or x.h % 2 or x.w % 2 or x.t.dtype != torch.float16:
+            raise ValueError(f"downsample conv: expected f16, {self.cin} channels and even H, W; got {x.t.dtype}, {x.c}, {x.h}x{x.w}")
         out = new_act(x.n, x.h // 2, x.w // 2, self.cout, x.t.dtype, x.t.device)
         d = self._desc(x.n, x.h, x.w, x.pitch, out.pitch)
         tiles = lib().elvis_conv_stats_tiles(C.byref(d))
@@ -443,6 +448,17 @@ def crop_copy(x: Act, h, w) -> Act:
     check(lib().elvis_crop_copy(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.pitch, h, w, x.c, out.pitch,
                                 _s(x.t)), x.t.device)
     return out
+
+
+def convert_act(x: Act, dtype) -> Act:
+    """Same tensor in another storage dtype (f16 <-> f32).  Widening keeps the producer's GroupNorm
+    partial sums (the values are unchanged); narrowing drops them (the stored values moved)."""
+    if x.t.dtype == dtype:
+        return x
+    out = torch.empty(x.t.shape, dtype=dtype, device=x.t.device)
+    check(lib().elvis_convert_act(ptr(x.t), x.dtype_code, ptr(out), L.dtype_code(dtype), x.n * x.h * x.w, x.pitch,
+                                  _s(x.t)), x.t.device)
+    return Act(out, x.c, x.stats if dtype == torch.float32 else None)
 
 
 # ----------------------------------------------------------------------------- DCT-slot kernels

@@ -25,13 +25,13 @@ from .recompose import (frames_to_device, frames_to_host, maps_to_device, rounds
 from .sinsr import SinSRModel
 from .weights import SinSRConfig
 
-_MODEL_CACHE: Dict[str, SinSRModel] = {}
+_MODEL_CACHE: Dict[tuple, tuple] = {}
 _MODEL_LOCK = threading.Lock()
 DEFAULT_SEED = 42  # the reference's default sampler seed (elvis.py:89, utils.py:103)
 
 
 def get_sinsr_model(device, *, cfg: Optional[SinSRConfig] = None, fp32: bool = False, weight_seed: int = 0,
-                    state_dict=None, fuse_gn: bool = True) -> SinSRModel:
+                    state_dict=None, fuse_gn: bool = True, precision: Optional[str] = None) -> SinSRModel:
     """Get or create the cached SinSR runtime for `device` (thread-safe, never freed - the
     reference's cache policy, elvis.py:2611-2637)."""
     dev = torch.device(device)
@@ -39,16 +39,19 @@ def get_sinsr_model(device, *, cfg: Optional[SinSRConfig] = None, fp32: bool = F
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     cfg = cfg or SinSRConfig()
-    key = f"{dev}_{hash(cfg)}_{fp32}_{weight_seed}_{id(state_dict) if state_dict is not None else 0}_{fuse_gn}"
+    # the key holds `cfg` itself (a frozen dataclass) and the identity of the caller's state_dict; the
+    # cache entry keeps a strong reference to that dict, so its id cannot be reused by another object
+    key = (str(dev), cfg, bool(fp32), precision, int(weight_seed), id(state_dict) if state_dict is not None else 0, bool(fuse_gn))
     with _MODEL_LOCK:
-        m = _MODEL_CACHE.get(key)
-        if m is None:
+        hit = _MODEL_CACHE.get(key)
+        if hit is None:
             try:
-                m = SinSRModel(cfg, state_dict, dev, torch.float32 if fp32 else torch.float16, weight_seed, fuse_gn)
+                m = SinSRModel(cfg, state_dict, dev, torch.float32 if fp32 else torch.float16, weight_seed, fuse_gn,
+                               precision=precision)
             except RuntimeError as exc:
                 raise RuntimeError(f"SinSR failed on {dev}: {exc}") from exc
-            _MODEL_CACHE[key] = m
-    return m
+            hit = _MODEL_CACHE[key] = (m, state_dict)
+    return hit[0]
 
 
 def sr4x_device(model: SinSRModel, lr_d: torch.Tensor, frame_indices: Sequence[int], seed: int = DEFAULT_SEED,
@@ -75,11 +78,12 @@ def get_sinsr_upsample_fn(device, *, scale: int = 2, seed: int = DEFAULT_SEED, f
 
     def upsample_fn(img: np.ndarray) -> np.ndarray:
         try:
-            d = frames_to_device([img], model.device)
-            out = sr4x_device(model, d, [frame_index], seed)
-            if scale == 2:
-                out = ops.area_downscale_u8(out, 2)
-            return frames_to_host(out)[0]
+            with torch.cuda.device(model.device):   # pool threads start on device 0 (P2, elvis.py:342-346)
+                d = frames_to_device([img], model.device)
+                out = sr4x_device(model, d, [frame_index], seed)
+                if scale == 2:
+                    out = ops.area_downscale_u8(out, 2)
+                return frames_to_host(out)[0]
         except RuntimeError as exc:
             raise RuntimeError(f"SinSR failed on {model.device}: {exc}") from exc
 
@@ -128,23 +132,24 @@ def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, leve
 
 def restore_frames_sinsr(frames: List[np.ndarray], downscale_maps: np.ndarray, block_size: int, device,
                          *, seed: int = DEFAULT_SEED, first_frame_index: int = 0, fp32: bool = False,
-                         schedule: str = "single4x", staged_2x: bool = False, cfg: Optional[SinSRConfig] = None,
-                         **_ignored) -> List[np.ndarray]:
+                         schedule: str = "staged", staged_2x: bool = False, cfg: Optional[SinSRConfig] = None,
+                         precision: Optional[str] = None, **_ignored) -> List[np.ndarray]:
     """Pure restoration function (no file IO, no parallelisation), drop-in for
     `restore_frames_realesrgan` (elvis.py:2640-2682): BGR uint8 frames + per-block log2
     downscale maps -> restored frames.
 
-    schedule="single4x" (default, the north-star path): one SinSR 4x call from the /4 level per
-    frame, whatever the map's maximum (README.md:50).  schedule="staged": the coarse-to-fine loop
-    of elvis.py:2570-2598 generalised to 4x stages (`staged_2x=True`: the reference's 2x-per-stage
-    loop with the 4x net area-halved per stage).
+    schedule="staged" (default: the reference's semantics): the coarse-to-fine loop of
+    elvis.py:2570-2598 generalised to 4x stages (`staged_2x=True`: the reference's 2x-per-stage loop
+    with the 4x net area-halved per stage).  schedule="single4x" (the north-star / benchmark path): one
+    SinSR 4x call from the /4 level per frame, whatever the map's maximum (README.md:50) - blocks of
+    level 1 lose the detail the staged loop would keep at the /2 stage.
     Unknown model kwargs of the reference call (model_name, tile, ...) are accepted and ignored
     (the `**kwargs` convention of the P3 surface, utils.py:1428).
     """
     if not frames:
         return []
     dev = torch.device(device)
-    model = get_sinsr_model(dev, cfg=cfg, fp32=fp32)
+    model = get_sinsr_model(dev, cfg=cfg, fp32=fp32, precision=precision)
     with torch.cuda.device(model.device):
         frames_d = frames_to_device(frames, model.device)
         n = frames_d.shape[0]
@@ -211,7 +216,7 @@ def restore_frames_rounds(frames: List[np.ndarray], maps: np.ndarray, block_size
 
 
 # ----------------------------------------------------------------------------- Blur / DCT slots
-_RESTORER_CACHE: Dict[str, object] = {}
+_RESTORER_CACHE: Dict[tuple, tuple] = {}
 
 
 def _get_restorer(kind: str, device, fp32: bool, cfg=None, state_dict=None):
@@ -220,9 +225,10 @@ def _get_restorer(kind: str, device, fp32: bool, cfg=None, state_dict=None):
     L.require_gpu(dev)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    key = f"{kind}_{dev}_{fp32}_{hash(cfg)}_{id(state_dict) if state_dict is not None else 0}"
+    key = (kind, str(dev), bool(fp32), cfg, id(state_dict) if state_dict is not None else 0)
     with _MODEL_LOCK:
-        m = _RESTORER_CACHE.get(key)
+        hit = _RESTORER_CACHE.get(key)
+        m = hit[0] if hit is not None else None
         if m is None:
             cls = SwinDeblur if kind == "blur" else DCNRestorer
             args = (cfg,) if cfg is not None else ()
@@ -230,7 +236,7 @@ def _get_restorer(kind: str, device, fp32: bool, cfg=None, state_dict=None):
                 m = cls(*args, state_dict=state_dict, device=dev, dtype=torch.float32 if fp32 else torch.float16)
             except RuntimeError as exc:
                 raise RuntimeError(f"{cls.__name__} failed on {dev}: {exc}") from exc
-            _RESTORER_CACHE[key] = m
+            _RESTORER_CACHE[key] = (m, state_dict)   # the strong reference keeps id(state_dict) unique
     return m
 
 

@@ -1,47 +1,66 @@
-"""Frame-parallel sharding helpers - the reference's P4 surface, host logic only.
+"""Frame-parallel sharding - the reference's P4 surface, host logic only.
 
-`ChunkSpec`, `chunk_for_devices`, `parallel_process_frames` and `resolve_device_list` keep the
-names, argument meaning and error behaviour of elvis.py:246-353 and elvis.py:451-530 so the
-existing pipeline can import them from here unchanged.  `rank_frame_range` applies the same
-split rule to torch.distributed ranks (one process per GPU).
+Interface kept from the reference so the pipeline can import these names unchanged:
+`ChunkSpec` (elvis.py:246), `chunk_for_devices` (elvis.py:255), `parallel_process_frames`
+(elvis.py:283), `_resolve_device_list` (elvis.py:451).  The bodies are written from that interface and
+from the golden tables in tests/golden/chunks.npz / devices_cpu.npz, around one primitive: the
+even split `rank_frame_range`, which is also what the one-process-per-GPU runner
+(`elvis_amd.distributed`) and the directory drivers (`elvis_amd.drivers`) use.
 """
 from __future__ import annotations
 
-from concurrent.futures import ThreadPoolExecutor, as_completed
+import re
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
-from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
 
+DeviceSpec = Union[int, str, torch.device]
+
 
 @dataclass
 class ChunkSpec:
-    """Specification for a processing chunk (elvis.py:246-252)."""
+    """A contiguous frame range [start, end) assigned to `device`; `chunk_id` orders the results."""
     start: int
     end: int
     device: torch.device
     chunk_id: int = 0
 
 
+def rank_frame_range(total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """[start, end) of part `rank` when `total` frames are dealt to `world_size` parts as evenly as
+    possible, larger parts first (the rule of elvis.py:264-271 and of `_split_ranges`,
+    elvis.py:3046-3060)."""
+    base, extra = divmod(max(total, 0), world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
 def chunk_for_devices(total: int, devices: List[torch.device], min_chunk_size: int = 1) -> List[ChunkSpec]:
-    """Contiguous split, one chunk per device; the first `total % D` devices get one extra
-    frame; empty chunks are dropped (elvis.py:255-280)."""
-    if not devices or total <= 0:
+    """One contiguous chunk per device (even split, larger chunks first); chunk_id = device position.
+    A device after the first whose share is below `min_chunk_size` gets no chunk, and - as in the
+    reference, pinned by the golden table - its share is not handed to anyone else: later chunks
+    continue where the last kept chunk ended."""
+    if total <= 0 or not devices:
         return []
-    num = len(devices)
-    base, rem = divmod(total, num)
+    world = len(devices)
     chunks: List[ChunkSpec] = []
-    start = 0
-    for idx, device in enumerate(devices):
-        size = base + (1 if idx < rem else 0)
-        if size < min_chunk_size and idx > 0:
-            continue  # (the reference skips the chunk without advancing `start`)
-        end = start + size
-        if end > start:
-            chunks.append(ChunkSpec(start=start, end=end, device=device, chunk_id=idx))
-        start = end
+    cursor = 0
+    for cid, dev in enumerate(devices):
+        lo, hi = rank_frame_range(total, world, cid)
+        size = hi - lo
+        if size > 0 and (cid == 0 or size >= min_chunk_size):
+            chunks.append(ChunkSpec(cursor, cursor + size, dev, cid))
+            cursor += size
     return chunks
+
+
+def _fixed_size_chunks(total: int, devices: Sequence[torch.device], chunk_size: int) -> List[ChunkSpec]:
+    """Chunks of `chunk_size` frames (the last one shorter) dealt round-robin to the devices."""
+    starts = range(0, total, chunk_size)
+    return [ChunkSpec(s, min(s + chunk_size, total), devices[cid % len(devices)], cid) for cid, s in enumerate(starts)]
 
 
 def parallel_process_frames(
@@ -51,119 +70,93 @@ def parallel_process_frames(
     chunk_size: Optional[int] = None,
     max_workers: Optional[int] = None,
 ) -> List[np.ndarray]:
-    """Thread-pool map of `process_fn(frames_chunk, device)` over chunks, results reassembled in
-    ascending chunk_id order (elvis.py:283-353).  `process_fn` must be thread-safe per device."""
+    """Run `process_fn(frames[start:end], device)` for every chunk on a thread pool and concatenate the
+    results in chunk order; a single chunk runs inline.  `process_fn` must be thread-safe per device
+    and must select its device itself (pool threads start on device 0)."""
     if not frames:
         return []
-    if not devices:
-        devices = [torch.device("cpu")]
-    n = len(frames)
-    if chunk_size is None:
-        chunks = chunk_for_devices(n, devices)
-    else:
-        chunks, cursor, cid = [], 0, 0
-        while cursor < n:
-            end = min(cursor + chunk_size, n)
-            chunks.append(ChunkSpec(start=cursor, end=end, device=devices[cid % len(devices)], chunk_id=cid))
-            cursor, cid = end, cid + 1
-    if not chunks:
+    devices = list(devices) or [torch.device("cpu")]
+    plan = (chunk_for_devices(len(frames), devices) if chunk_size is None
+            else _fixed_size_chunks(len(frames), devices, chunk_size))
+    if not plan:
         return []
-    if len(chunks) == 1:
-        c = chunks[0]
+
+    def run(c: ChunkSpec) -> List[np.ndarray]:
         return process_fn(frames[c.start:c.end], c.device)
-    results: Dict[int, List[np.ndarray]] = {}
-    workers = max_workers or min(len(chunks), len(devices))
 
-    def _run(chunk: ChunkSpec) -> Tuple[int, List[np.ndarray]]:
-        return chunk.chunk_id, process_fn(frames[chunk.start:chunk.end], chunk.device)
+    if len(plan) == 1:
+        return run(plan[0])
+    with ThreadPoolExecutor(max_workers=max_workers or min(len(plan), len(devices))) as pool:
+        parts = list(pool.map(run, plan))   # map() yields in submission (= chunk_id) order
+    return [frame for part in parts for frame in part]
 
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        futures = {ex.submit(_run, c): c for c in chunks}
-        for fut in as_completed(futures):
-            cid, out = fut.result()
-            results[cid] = out
-    output: List[np.ndarray] = []
-    for c in sorted(chunks, key=lambda c: c.chunk_id):
-        output.extend(results[c.chunk_id])
-    return output
+
+# ----------------------------------------------------------------------------- device specs
+_CUDA_SPEC = re.compile(r"^cuda(?::(?P<index>.*))?$")
+
+
+def _parse_device(spec: DeviceSpec, gpu_count: int) -> torch.device:
+    """One specifier -> torch.device, validated against the visible GPU count.  Accepted forms:
+    int n | "cuda" | "cuda:n" | torch.device | any other torch device string ("cpu", ...)."""
+    if isinstance(spec, torch.device):
+        dev = spec
+    elif isinstance(spec, int) and not isinstance(spec, bool):
+        if gpu_count == 0:
+            raise ValueError(f"device index {spec} given but no GPU is visible")
+        dev = torch.device("cuda", spec) if spec >= 0 else None
+        if dev is None:
+            raise ValueError(f"device index {spec} is negative")
+    else:
+        text = str(spec)
+        m = _CUDA_SPEC.match(text)
+        if m is None:
+            dev = torch.device(text)
+        else:
+            if gpu_count == 0:
+                raise ValueError(f"'{text}' requested but no GPU is visible")
+            idx_text = m.group("index")
+            if not idx_text:                      # "cuda" / "cuda:" -> the current device
+                dev = torch.device("cuda")
+            elif idx_text.isdigit():
+                dev = torch.device("cuda", int(idx_text))
+            else:
+                raise ValueError(f"malformed device string '{text}'")
+    if dev.type == "cuda" and (dev.index or 0) >= gpu_count:
+        raise ValueError(f"{dev} is not available: {gpu_count} GPU(s) visible")
+    return dev
+
+
+def _unique(devs: Iterable[torch.device]) -> List[torch.device]:
+    seen, out = set(), []
+    for d in devs:
+        key = (d.type, (d.index or 0) if d.type == "cuda" else d.index)   # "cuda" and "cuda:0" are one device
+        if key not in seen:
+            seen.add(key)
+            out.append(d)
+    return out
 
 
 def resolve_device_list(
-    devices: Optional[Sequence[Union[int, str, torch.device]]],
+    devices: Optional[Sequence[DeviceSpec]],
     *,
     prefer_cuda: bool = True,
     allow_cpu_fallback: bool = True,
 ) -> List[torch.device]:
-    """Normalise device specifiers into unique torch.device entries (elvis.py:451-530).
-    "cuda:N" is what PyTorch-ROCm calls the MI355X devices too."""
+    """Normalise device specifiers into a list of distinct torch.device entries, first occurrence
+    first.  No specifiers: every visible GPU ("cuda:N" is what PyTorch-ROCm calls the MI355X devices),
+    else the CPU if `allow_cpu_fallback`.  Anything unusable raises ValueError."""
     gpu_count = torch.cuda.device_count() if torch.cuda.is_available() else 0
-
-    def norm(spec) -> torch.device:
-        if isinstance(spec, torch.device):
-            dev = spec
-        elif isinstance(spec, int):
-            if not torch.cuda.is_available():
-                raise ValueError("CUDA device indices were provided but no CUDA devices are available.")
-            if spec < 0 or spec >= gpu_count:
-                raise ValueError(f"Requested CUDA device index {spec} is out of range.")
-            dev = torch.device(f"cuda:{spec}")
-        else:
-            s = str(spec)
-            if s.startswith("cuda"):
-                if not torch.cuda.is_available():
-                    raise ValueError("CUDA devices were requested but CUDA is not available.")
-                if s in ("cuda", "cuda:"):
-                    dev = torch.device("cuda")
-                else:
-                    try:
-                        idx = int(s.split(":", 1)[1])
-                    except (IndexError, ValueError):
-                        raise ValueError(f"Invalid CUDA device string '{s}'.") from None
-                    if idx < 0 or idx >= gpu_count:
-                        raise ValueError(f"Requested CUDA device {s} exceeds detected count {gpu_count}.")
-                    dev = torch.device(f"cuda:{idx}")
-            else:
-                dev = torch.device(s)
-        if dev.type == "cuda":
-            idx = dev.index if dev.index is not None else 0
-            if idx < 0 or idx >= gpu_count:
-                raise ValueError(f"Requested CUDA device {idx} is not available. Detected {gpu_count} device(s).")
-        return dev
-
-    if not devices:
-        if prefer_cuda and gpu_count > 0:
-            specs: Sequence = [f"cuda:{i}" for i in range(gpu_count)]
-        elif allow_cpu_fallback:
-            specs = ["cpu"]
-        else:
-            raise ValueError("No CUDA devices available and CPU fallback disabled.")
+    if devices:
+        resolved = _unique(_parse_device(s, gpu_count) for s in devices)
+    elif prefer_cuda and gpu_count:
+        resolved = [torch.device("cuda", i) for i in range(gpu_count)]
     else:
-        specs = devices
-    out: List[torch.device] = []
-    seen = set()
-    for spec in specs:
-        dev = norm(spec)
-        key = str(dev)
-        if dev.type == "cuda":
-            key = f"cuda:{dev.index if dev.index is not None else 0}"
-        if key in seen:
-            continue
-        seen.add(key)
-        out.append(dev)
-    if not out:
-        if allow_cpu_fallback:
-            out.append(torch.device("cpu"))
-        else:
-            raise ValueError("No valid compute devices resolved from the provided specification.")
-    return out
+        resolved = []
+    if resolved:
+        return resolved
+    if not allow_cpu_fallback:
+        raise ValueError("no usable compute device and the CPU fallback is disabled")
+    return [torch.device("cpu")]
 
 
 _resolve_device_list = resolve_device_list  # the reference's private name (elvis.py:451)
-
-
-def rank_frame_range(total: int, world_size: int, rank: int) -> Tuple[int, int]:
-    """[start,end) of the frames rank `rank` owns under the chunk_for_devices rule
-    (elvis.py:264-271; same rule as _split_ranges, elvis.py:3046-3060)."""
-    base, rem = divmod(total, world_size)
-    start = rank * base + min(rank, rem)
-    return start, start + base + (1 if rank < rem else 0)

@@ -154,9 +154,25 @@ class _SwinLayer:
 class SinSRModel:
     """Weights resident in HBM, packed once; `forward` runs one batch of LR frames."""
 
+    # Sections of the graph that may run at different precisions (precision="mixed[:sec+sec...]" runs the
+    # listed sections in f16 and the rest in fp32; tools/precision_study.py, DESIGN.md 4.1).
+    SECTIONS = ("enc0", "enc1", "enc2", "unet", "dec2", "dec1", "dec0")
+    MIXED_F16_DEFAULT = ("dec0",)
+
     def __init__(self, cfg: SinSRConfig = SinSRConfig(), state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = True):
+                 device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = True,
+                 precision: Optional[str] = None):
         self.cfg, self.device, self.dtype, self.fuse_gn = cfg, torch.device(device), dtype, fuse_gn
+        self.sec_dtype = {sec: dtype for sec in self.SECTIONS}
+        if precision is not None and precision.startswith("mixed"):
+            f16 = tuple(precision.split(":", 1)[1].split("+")) if ":" in precision else self.MIXED_F16_DEFAULT
+            unknown = [sec for sec in f16 if sec not in self.SECTIONS]
+            if unknown:
+                raise ValueError(f"unknown section(s) {unknown}; sections are {self.SECTIONS}")
+            self.sec_dtype = {sec: (torch.float16 if sec in f16 else torch.float32) for sec in self.SECTIONS}
+            self.dtype = self.sec_dtype["unet"]
+        elif precision not in (None, "f16", "f32"):
+            raise ValueError(f"unknown precision '{precision}'")
         import os
         self.subpixel_up = not os.environ.get("ELVIS_NO_SUBPIXEL")
         sd = state_dict if state_dict is not None else make_sinsr_weights(cfg, weight_seed)
@@ -168,7 +184,7 @@ class SinSRModel:
 
     # ------------------------------------------------------------------ construction
     def _build_unet(self, sd):
-        cfg, dev, dt = self.cfg, self.device, self.dtype
+        cfg, dev, dt = self.cfg, self.device, self.sec_dtype["unet"]
         # timestep path: load-time only, always in fp32 kernels
         te0 = _linear(sd, "model.time_embed.0", torch.float32, dev)
         te2 = _linear(sd, "model.time_embed.2", torch.float32, dev)
@@ -218,42 +234,52 @@ class SinSRModel:
         self.u_out_norm = _GN(sd, "model.out.0", dev)
         self.u_out_conv = _conv(sd, "model.out.2", dt, dev, plan["out_ch"])
 
-    def _build_ae(self, sd):
-        cfg, dev, dt = self.cfg, self.device, self.dtype
-        ch, mults, nrb, g = cfg.ae_ch, cfg.ae_ch_mult, cfg.ae_num_res_blocks, cfg.gn_groups
+    def _ae_section(self, side: str, lvl: int) -> str:
+        """Section of autoencoder level `lvl` (0 = full resolution); deeper levels than the named ones
+        (narrow test configs have the same three) fold into the last."""
+        return f"{side}{min(lvl, 2)}"
 
-        def rb(p, cin, cout):
+    def _build_ae(self, sd):
+        cfg, dev = self.cfg, self.device
+        ch, mults, nrb, g = cfg.ae_ch, cfg.ae_ch_mult, cfg.ae_num_res_blocks, cfg.gn_groups
+        last = len(mults) - 1
+
+        def rb(p, cin, cout, dt):
             names = (p + ".norm1", p + ".conv1", p + ".norm2", p + ".conv2", p + ".nin_shortcut")
             return _ResBlock(sd, names, cin, 0, cout, dt, dev, g, 1e-6)
 
-        self.e_conv_in = _conv(sd, "ae.encoder.conv_in", dt, dev, 3)
+        self.e_conv_in = _conv(sd, "ae.encoder.conv_in", self.sec_dtype["enc0"], dev, 3)
         self.e_down = []
         cin = ch
         for lvl, m in enumerate(mults):
+            dt = self.sec_dtype[self._ae_section("enc", lvl)]
             blocks = []
             for b in range(nrb):
-                blocks.append(rb(f"ae.encoder.down.{lvl}.block.{b}", cin, ch * m))
+                blocks.append(rb(f"ae.encoder.down.{lvl}.block.{b}", cin, ch * m, dt))
                 cin = ch * m
-            ds = _DownConv(sd, f"ae.encoder.down.{lvl}.downsample.conv", dt, dev, cin) if lvl != len(mults) - 1 else None
-            self.e_down.append((blocks, ds))
-        self.e_mid = [rb("ae.encoder.mid.block_1", cin, cin), rb("ae.encoder.mid.block_2", cin, cin)]
+            ds = _DownConv(sd, f"ae.encoder.down.{lvl}.downsample.conv", dt, dev, cin) if lvl != last else None
+            self.e_down.append((blocks, ds, dt))
+        dt = self.sec_dtype[self._ae_section("enc", last)]
+        self.e_mid = [rb("ae.encoder.mid.block_1", cin, cin, dt), rb("ae.encoder.mid.block_2", cin, cin, dt)]
         self.e_norm_out = _GN(sd, "ae.encoder.norm_out", dev)
         self.e_conv_out = _conv(sd, "ae.encoder.conv_out", dt, dev, cin)
         self.quant_conv = _conv(sd, "ae.quant_conv", dt, dev, cfg.z_channels)
+        dt = self.sec_dtype[self._ae_section("dec", last)]
         self.post_quant_conv = _conv(sd, "ae.post_quant_conv", dt, dev, cfg.embed_dim)
         cin = ch * mults[-1]
         self.d_conv_in = _conv(sd, "ae.decoder.conv_in", dt, dev, cfg.z_channels)
-        self.d_mid = [rb("ae.decoder.mid.block_1", cin, cin), rb("ae.decoder.mid.block_2", cin, cin)]
+        self.d_mid = [rb("ae.decoder.mid.block_1", cin, cin, dt), rb("ae.decoder.mid.block_2", cin, cin, dt)]
         self.d_up = []
         for lvl in reversed(range(len(mults))):
+            dt = self.sec_dtype[self._ae_section("dec", lvl)]
             blocks = []
             for b in range(nrb + 1):
-                blocks.append(rb(f"ae.decoder.up.{lvl}.block.{b}", cin, ch * mults[lvl]))
+                blocks.append(rb(f"ae.decoder.up.{lvl}.block.{b}", cin, ch * mults[lvl], dt))
                 cin = ch * mults[lvl]
             us = _UpConv(sd, f"ae.decoder.up.{lvl}.upsample.conv", dt, dev, cin, self.subpixel_up) if lvl != 0 else None
-            self.d_up.append((blocks, us))
+            self.d_up.append((blocks, us, dt))
         self.d_norm_out = _GN(sd, "ae.decoder.norm_out", dev)
-        self.d_conv_out = _conv(sd, "ae.decoder.conv_out", dt, dev, cin)
+        self.d_conv_out = _conv(sd, "ae.decoder.conv_out", self.sec_dtype["dec0"], dev, cin)
 
     # ------------------------------------------------------------------ stages
     def _gn_silu_conv(self, x: Act, norm: _GN, conv: PackedConv, eps: float) -> Act:
@@ -289,8 +315,9 @@ class SinSRModel:
         return self._gn_silu_conv(h, self.u_out_norm, self.u_out_conv, 1e-5)
 
     def encode(self, x: Act) -> Act:
-        h = self.e_conv_in(x, want_stats=self.fuse_gn)
-        for blocks, ds in self.e_down:
+        h = self.e_conv_in(ops.convert_act(x, self.sec_dtype["enc0"]), want_stats=self.fuse_gn)
+        for blocks, ds, dt in self.e_down:
+            h = ops.convert_act(h, dt)
             for b in blocks:
                 h = b(h, fuse_gn=self.fuse_gn)
             if ds is not None:
@@ -304,10 +331,12 @@ class SinSRModel:
         idx = None
         if self.cfg.quantize if quantize is None else quantize:
             z, idx = ops.vq_nearest(z, self.codebook, want_idx=True)
+        z = ops.convert_act(z, self.sec_dtype[self._ae_section("dec", len(self.cfg.ae_ch_mult) - 1)])
         h = self.d_conv_in(self.post_quant_conv(z), want_stats=self.fuse_gn)
         for b in self.d_mid:
             h = b(h, fuse_gn=self.fuse_gn)
-        for blocks, us in self.d_up:
+        for blocks, us, dt in self.d_up:
+            h = ops.convert_act(h, dt)
             for b in blocks:
                 h = b(h, fuse_gn=self.fuse_gn)
             if us is not None:
@@ -328,9 +357,9 @@ class SinSRModel:
         hp, wp = self.padded_latent_shape(h, w)
         if tuple(noise.shape) != (n, cfg.latent_ch, hp, wp):
             raise ValueError(f"noise must be {(n, cfg.latent_ch, hp, wp)}, got {tuple(noise.shape)}")
-        y = ops.u8_to_float(lr_u8, self.dtype, 2.0, -1.0, swap_rb=swap_rb, div255=True)
-        y_up = ops.bicubic_upsample(y, cfg.sf)
-        z_y = self.encode(y_up)
+        y = ops.u8_to_float(lr_u8, self.dtype, 2.0, -1.0, swap_rb=swap_rb, div255=True)   # self.dtype = the UNet's
+        y_up = ops.bicubic_upsample(ops.convert_act(y, self.sec_dtype["enc0"]), cfg.sf)
+        z_y = ops.convert_act(self.encode(y_up), self.dtype)
         if stages is not None:
             stages["y_up"], stages["z_y"] = y_up, z_y
         del y_up
@@ -344,7 +373,7 @@ class SinSRModel:
             z0 = ops.crop_copy(z0, h, w)
         if stages is not None:
             stages["z0"] = z0
-        dec = self.decode(z0)
+        dec = self.decode(z0)   # (converts z0 to the decoder's first section itself)
         if stages is not None:
             stages["dec"] = dec
         return ops.float_to_u8(dec, 0.5, 0.5, mode=0, swap_rb=swap_rb, want_f32=want_f32)

@@ -111,31 +111,47 @@ def resource_aware_restore(restore_fn: Callable, frames: List[np.ndarray], tile_
     return frames_to_host(final)
 
 
+def _block_span(lo: int, hi: int, block: int, limit: int) -> slice:
+    """Blocks that pixel range [lo, hi) touches, plus the one guard block after it that the reference's
+    gate also inspects, clipped to the map."""
+    return slice(lo // block, min(-(-hi // block) + 1, limit))
+
+
 def adaptive_restore(restore_fn: Callable, frames: List[np.ndarray], degradation_maps: Optional[np.ndarray] = None,
                      block_size: int = 16, tile_coords: Optional[Tuple[int, int, int, int, int, int]] = None,
                      threshold: float = 0.0, **kwargs) -> List[np.ndarray]:
-    """Skip `restore_fn` for tiles whose degradation-map slice never exceeds `threshold`
-    (utils.py:329-394).  Integer compare on a tiny host array: host logic."""
-    if degradation_maps is None:
-        return restore_fn(frames=frames, **kwargs)
-    should = False
-    if tile_coords:
+    """Degradation gate for the tiler (interface of utils.py:329-394, meant to be `functools.partial`-ed
+    around a `restore_fn`): a tile whose window of the FULL `(N, By, Bx)` map holds no value above
+    `threshold` is returned untouched; every other call goes to `restore_fn(frames=frames, **kwargs)`.
+    Without maps or without `tile_coords` there is nothing to gate on and the restorer always runs.
+    An integer compare on a few map entries: host logic (behaviour pinned by tests/golden/gate.npz)."""
+    if degradation_maps is not None and tile_coords:
+        maps = np.asarray(degradation_maps)
         t0, t1, y0, y1, x0, x1 = tile_coords
-        by0 = y0 // block_size
-        by1 = (y1 + block_size - 1) // block_size + 1
-        bx0 = x0 // block_size
-        bx1 = (x1 + block_size - 1) // block_size + 1
-        hb, wb = degradation_maps.shape[1:]
-        by1, bx1 = min(by1, hb), min(bx1, wb)
-        nm = len(degradation_maps)
-        tm0, tm1 = min(t0, nm), min(t1, nm)
-        if tm0 < tm1:
-            sl = degradation_maps[tm0:tm1, by0:by1, bx0:bx1]
-            if sl.size > 0 and np.max(sl) > threshold:
-                should = True
-    else:
-        should = True
-    return restore_fn(frames=frames, **kwargs) if should else frames
+        window = maps[min(t0, len(maps)):min(t1, len(maps)),
+                      _block_span(y0, y1, block_size, maps.shape[1]),
+                      _block_span(x0, x1, block_size, maps.shape[2])]
+        if not (window > threshold).any():
+            return frames
+    return restore_fn(frames=frames, **kwargs)
+
+
+def _extract_tile_with_halo(frame: np.ndarray, y: int, x: int, tile_h: int, tile_w: int, halo: int):
+    """Tile (y, x, tile_h, tile_w) of `frame` grown by `halo` pixels on every side where the frame allows,
+    as a copy, with the (top, left, bottom, right) bounds that crop the halo off a same-size result
+    (interface of utils.py:1227-1250; pinned by tests/golden/tiler.npz).  Index math on the host."""
+    h, w = frame.shape[:2]
+    top, left = min(halo, max(y, 0)), min(halo, max(x, 0))
+    tile = frame[y - top:min(h, y + tile_h + halo), x - left:min(w, x + tile_w + halo)].copy()
+    return tile, (top, left, top + tile_h, left + tile_w)
+
+
+extract_tile_with_halo = _extract_tile_with_halo
+
+
+def _nearest_rows(src_n: int, dst_n: int) -> np.ndarray:
+    """INTER_NEAREST source index of every destination index: floor(dst * src_n / dst_n)."""
+    return (np.arange(dst_n, dtype=np.int64) * src_n) // dst_n
 
 
 def blended_restoration(frames, degradation_maps, block_size, alpha=1.0, restore_fn=None, device="cuda", **kwargs):
@@ -149,9 +165,11 @@ def blended_restoration(frames, degradation_maps, block_size, alpha=1.0, restore
     dev = _accum_device(device)
     h, w = frames[0].shape[:2]
     by, bx = h // block_size, w // block_size
-    maps = np.stack([np.asarray(d) for d in degradation_maps])
-    if maps.shape[1:] != (by, bx):
-        raise ValueError(f"degradation maps {maps.shape[1:]} do not match the block grid {(by, bx)}")
+    maps = np.stack([np.asarray(d) for d in degradation_maps])[: len(frames)]
+    if len(maps) != len(frames):
+        raise ValueError(f"{len(maps)} degradation maps for {len(frames)} frames")
+    if maps.shape[1:] != (by, bx):   # the reference NEAREST-resizes a map of another shape to the grid (utils.py:1587)
+        maps = maps[:, _nearest_rows(maps.shape[1], by)][:, :, _nearest_rows(maps.shape[2], bx)]
     o = frames_to_device(frames, dev)
     r = frames_to_device(restored, dev)
     m = maps_to_device((maps > 0).astype(np.int32), len(frames), dev)

@@ -221,6 +221,11 @@ int elvis_pad_reflect_axpy(const void* x, void* y, int dtype, int n, int h, int 
 int elvis_crop_copy(const void* x, void* y, int dtype, int n, int h_in, int w_in, int pitch_in, int h,
                     int w, int c, int pitch_out, elvis_stream_t stream);
 
+/* y = (dst dtype) x for a pitched NHWC tensor of `pixels` x `pitch` elements (pitch % 8 == 0; f16 <-> f32):
+ * the section boundaries of the mixed-precision mode.  No reference counterpart. */
+int elvis_convert_act(const void* x, int src_dtype, void* y, int dst_dtype, long long pixels, int pitch,
+                      elvis_stream_t stream);
+
 /* ------------------------------------------------------------------ DCT slot (LaplacianVCAR-style) */
 
 /* DCNv2 modulated deformable 3x3 convolution (stride 1, pad 1, dilation 1), NHWC.

@@ -29,7 +29,7 @@ def _keep_mask(level_map):
 def test_sinsr_1080p_properties(gpu_device):
     from elvis_amd import restore
     frames, maps, _ = _clip(3, 1, 3)
-    out = restore.restore_frames_sinsr(frames, maps, B, gpu_device)
+    out = restore.restore_frames_sinsr(frames, maps, B, gpu_device, schedule="single4x")
     assert len(out) == 3 and all(o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
     # level-0 blocks are the decoded input, bit for bit (elvis.py:2584-2595 paste rule)
     assert np.array_equal(out[2], frames[2])
@@ -38,9 +38,9 @@ def test_sinsr_1080p_properties(gpu_device):
         assert np.array_equal(out[i][k], frames[i][k])
         assert not np.array_equal(out[i][~k], frames[i][~k])
     # bit-reproducible, and independent of how the clip is split across calls / ranks
-    again = restore.restore_frames_sinsr(frames, maps, B, gpu_device)
-    a = restore.restore_frames_sinsr(frames[:1], maps[:1], B, gpu_device, first_frame_index=0)
-    b = restore.restore_frames_sinsr(frames[1:], maps[1:], B, gpu_device, first_frame_index=1)
+    again = restore.restore_frames_sinsr(frames, maps, B, gpu_device, schedule="single4x")
+    a = restore.restore_frames_sinsr(frames[:1], maps[:1], B, gpu_device, first_frame_index=0, schedule="single4x")
+    b = restore.restore_frames_sinsr(frames[1:], maps[1:], B, gpu_device, first_frame_index=1, schedule="single4x")
     for x, y, z in zip(out, again, a + b):
         assert np.array_equal(x, y) and np.array_equal(x, z)
     # ... and of the frames-per-invocation batching inside a call
