@@ -18,6 +18,7 @@
 // f32 mode is exact IEEE fp32 FMA chains (parity mode); f16 mode accumulates in fp32.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -1426,15 +1427,22 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false,
                            : (TWO ? 1 : 2) * (size_t)((TY + KS - 1) * (HALO_TX + KS - 1) * 64) + ((TWO || KS == 2) ? 2 : 3) * KS * (size_t)TCO * 64;
     const size_t lds = lds_fixed + (PRO ? (size_t)a.nkc * 4 * 2 * DT<T>::VEC * sizeof(float) : 0);
     ELVIS_REQUIRE(lds <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS needed (too many input channels)", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return ELVIS_E_RUNTIME;
+    {   // the 160 KB opt-in is a per-device function attribute: set it once per (instantiation, device),
+        // under a lock - P2 calls this from pool threads, one per device (elvis.py:342-346)
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        std::lock_guard<std::mutex> guard(mu);
+        if (!attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) {
+                elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+                return ELVIS_E_RUNTIME;
+            }
+            attr_set[dev] = true;
         }
-        attr_set = true;
     }
     long long nblk = (long long)a.n_co_tiles * a.tiles_x * a.tiles_y * a.n;
     ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");

@@ -238,6 +238,24 @@ class PackedConv:
 # the events are recorded on the stream the kernel is launched on (torch's current stream).
 CONV_PROFILER = None
 CONV_SHAPES = None    # optional parallel list of (n,h,w,cin,cout,ksize,stride,prologue,residual) per launch
+# Same idea for the non-conv hot kernels (window attention, DCNv2): (kernel, bound "mfma"|"hbm", algorithmic
+# FLOPs or bytes, start_evt, end_evt)
+KERNEL_PROFILER = None
+
+
+class _Timed:
+    def __init__(self, name, bound, work):
+        self.rec = (name, bound, work) if KERNEL_PROFILER is not None else None
+
+    def __enter__(self):
+        if self.rec:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.rec and KERNEL_PROFILER is not None:
+            self.e1.record()
+            KERNEL_PROFILER.append(self.rec + (self.e0, self.e1))
 
 
 def conv_kernel_name(d) -> str:
@@ -415,9 +433,11 @@ def layernorm(x: Act, gamma, beta, eps=1e-5, out: Optional[Act] = None) -> Act:
 
 def window_attention(qkv: Act, heads, head_dim, ws, shift, bias_table, scale) -> Act:
     out = new_act(qkv.n, qkv.h, qkv.w, heads * head_dim, qkv.t.dtype, qkv.t.device, zero=False)
-    check(lib().elvis_window_attention(ptr(qkv.t), ptr(out.t), qkv.dtype_code, qkv.n, qkv.h, qkv.w, heads, head_dim,
-                                       ws, shift, qkv.pitch, out.pitch, ptr(bias_table), float(scale), _s(qkv.t)),
-          qkv.t.device)
+    t = ws * ws
+    with _Timed("window_attention", "mfma", 4.0 * t * t * head_dim * heads * qkv.n * (qkv.h // ws) * (qkv.w // ws)):
+        check(lib().elvis_window_attention(ptr(qkv.t), ptr(out.t), qkv.dtype_code, qkv.n, qkv.h, qkv.w, heads, head_dim,
+                                           ws, shift, qkv.pitch, out.pitch, ptr(bias_table), float(scale), _s(qkv.t)),
+              qkv.t.device)
     return out
 
 
@@ -467,8 +487,13 @@ def dcnv2(x: Act, om: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], g
     """Modulated deformable 3x3 conv.  om: offsets (18*G) then masks (9*G) channels; weight
     [cout, cin, 3, 3] tensor already in the activation dtype on the device."""
     out = new_act(x.n, x.h, x.w, cout, x.t.dtype, x.t.device)
-    check(lib().elvis_dcnv2(ptr(x.t), ptr(om.t), ptr(weight), ptr(bias), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c,
-                            x.pitch, groups, om.pitch, int(mask_sigmoid), cout, out.pitch, act, _s(x.t)), x.t.device)
+    es = x.t.element_size()
+    # algorithmic bytes per output pixel: the 27*G offset/mask channels, 9 taps x 4 bilinear corners of every
+    # input channel, the output channels (SURVEY.md 8d)
+    px_bytes = (27 * groups + 9 * 4 * x.c + cout) * es
+    with _Timed("dcnv2", "hbm", float(px_bytes) * x.n * x.h * x.w):
+        check(lib().elvis_dcnv2(ptr(x.t), ptr(om.t), ptr(weight), ptr(bias), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c,
+                                x.pitch, groups, om.pitch, int(mask_sigmoid), cout, out.pitch, act, _s(x.t)), x.t.device)
     return out
 
 

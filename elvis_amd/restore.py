@@ -93,19 +93,21 @@ def get_sinsr_upsample_fn(device, *, scale: int = 2, seed: int = DEFAULT_SEED, f
 def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, levels_d: torch.Tensor, block_size: int,
                                  frame_indices: Sequence[int], seed: int = DEFAULT_SEED, swap_rb: bool = True,
                                  noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                                 batch: int = 6) -> torch.Tensor:
+                                 batch: int = 6, active: Optional[Sequence[bool]] = None) -> torch.Tensor:
     """The north-star Downsample path, fully on device: whole frame /4 (INTER_AREA, elvis.py:2565)
     -> ONE SinSR 4x call (README.md:50) -> final-stage paste of elvis.py:2584-2595 at f=1
     (`level == 0 ? decoded frame : SR`).  Frames whose map is all zero skip the network.
     `noise` ([n,3,Hp,Wp] f32, resident) may be passed to keep host RNG out of a timed region.
     `batch` frames go through the network together (fills the GPU better on the UNet's small
-    levels; results are identical - every op is per-sample)."""
+    levels; results are identical - every op is per-sample).  `active[i]` (does frame i have any
+    level > 0) may be passed from the host copy of the map to avoid a device->host sync here."""
     n, H, W, _ = frames_d.shape
     if H % 4 or W % 4 or H % block_size or W % block_size:
         raise ValueError("Image dimensions must be divisible by block_size and by 4.")
     if out is None:
         out = torch.empty_like(frames_d)
-    active = (levels_d > 0).flatten(1).any(dim=1).tolist()
+    if active is None:
+        active = (levels_d > 0).flatten(1).any(dim=1).tolist()
     with torch.cuda.device(model.device):
         todo = [i for i in range(n) if active[i]]
         for i in range(n):
@@ -128,6 +130,87 @@ def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, leve
             else:
                 out[sel] = ops.recompose_u8(f, sr, lv, block_size, 0)
     return out
+
+
+class _HostClipPipeline:
+    """Persistent staging for `restore_clip_single4x_host`: device buffers for one clip, a pinned host
+    buffer for the sampler noise, two copy streams and a small thread pool for the noise generator."""
+
+    def __init__(self, model: SinSRModel, n: int, H: int, W: int, by: int, bx: int):
+        from concurrent.futures import ThreadPoolExecutor
+        dev = model.device
+        hp, wp = model.padded_latent_shape(H // 4, W // 4)
+        self.shape = (n, H, W, by, bx)
+        self.frames_d = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+        self.out_d = torch.empty_like(self.frames_d)
+        self.levels_d = torch.empty((n, by, bx), dtype=torch.int32, device=dev)
+        self.noise_d = torch.empty((n, model.cfg.latent_ch, hp, wp), dtype=torch.float32, device=dev)
+        self.noise_h = torch.empty((n, model.cfg.latent_ch, hp, wp), dtype=torch.float32).pin_memory()
+        self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        self.pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="elvis-noise")
+
+
+_PIPELINES: Dict[tuple, _HostClipPipeline] = {}
+
+
+def restore_clip_single4x_host(model: SinSRModel, frames_h: torch.Tensor, levels_h: torch.Tensor, block_size: int,
+                               frame_indices: Sequence[int], out_h: Optional[torch.Tensor] = None,
+                               seed: int = DEFAULT_SEED, swap_rb: bool = True, batch: int = 15,
+                               want_device: bool = False):
+    """Host-to-host form of `restore_clip_single4x_device` (the metric's timed region):
+    `frames_h` [n,H,W,3] uint8 and `levels_h` [n,By,Bx] int32 in host memory (pinned for full-rate
+    PCIe) -> restored frames in `out_h` (host, pinned).  Per batch of `batch` frames: upload on a copy
+    stream, sampler noise generated by a thread pool (torch CPU generator keyed on the global frame
+    index, exactly `weights.frame_noise`) into pinned memory and uploaded, network + recompose on the
+    compute stream, download on a second copy stream - so transfers and the noise generator overlap the
+    previous / next batch's compute.  Returns after everything has been ENQUEUED; synchronise the device
+    (or `out_h`'s consumers) before reading `out_h`.  `want_device=True` also returns the restored clip's
+    HBM buffer (valid until the next call with the same model and shape) for a following all-gather."""
+    n, H, W, _ = frames_h.shape
+    by, bx = levels_h.shape[1:]
+    if H % 4 or W % 4 or H % block_size or W % block_size:
+        raise ValueError("Image dimensions must be divisible by block_size and by 4.")
+    if frames_h.is_cuda or levels_h.is_cuda or frames_h.dtype != torch.uint8 or levels_h.dtype != torch.int32:
+        raise ValueError("restore_clip_single4x_host takes host uint8 frames and host int32 maps")
+    if out_h is None:
+        out_h = torch.empty((n, H, W, 3), dtype=torch.uint8).pin_memory()
+    key = (id(model), n, H, W, by, bx)
+    with _MODEL_LOCK:
+        pl = _PIPELINES.get(key)
+        if pl is None:
+            with torch.cuda.device(model.device):
+                pl = _PIPELINES[key] = _HostClipPipeline(model, n, H, W, by, bx)
+    active = (levels_h > 0).flatten(1).any(dim=1).tolist()
+    cfg, (hp, wp) = model.cfg, pl.noise_h.shape[2:]
+
+    def gen(i):   # bit-identical to weights.frame_noise(cfg, seed, frame_indices[i], hp, wp)
+        g = torch.Generator().manual_seed(int(seed) * 1000003 + int(frame_indices[i]))
+        torch.randn((1, cfg.latent_ch, hp, wp), generator=g, dtype=torch.float32, out=pl.noise_h[i:i + 1])
+
+    step = max(1, batch)
+    futures = {i: pl.pool.submit(gen, i) for i in range(n) if active[i]}
+    with torch.cuda.device(model.device):
+        compute = torch.cuda.current_stream(model.device)
+        pl.h2d.wait_stream(compute)   # the previous call's kernels may still read the staging buffers
+        pl.d2h.wait_stream(compute)
+        for s0 in range(0, n, step):
+            sel = slice(s0, min(s0 + step, n))
+            for i in range(sel.start, sel.stop):
+                if i in futures:
+                    futures[i].result()
+            with torch.cuda.stream(pl.h2d):
+                pl.frames_d[sel].copy_(frames_h[sel], non_blocking=True)
+                pl.levels_d[sel].copy_(levels_h[sel], non_blocking=True)
+                pl.noise_d[sel].copy_(pl.noise_h[sel], non_blocking=True)
+            compute.wait_stream(pl.h2d)
+            restore_clip_single4x_device(model, pl.frames_d[sel], pl.levels_d[sel], block_size,
+                                         list(frame_indices[sel]), seed, swap_rb, noise=pl.noise_d[sel],
+                                         out=pl.out_d[sel], batch=step, active=active[sel])
+            pl.d2h.wait_stream(compute)
+            with torch.cuda.stream(pl.d2h):
+                out_h[sel].copy_(pl.out_d[sel], non_blocking=True)
+        compute.wait_stream(pl.d2h)   # a device synchronize / later kernel now also covers the downloads
+    return (out_h, pl.out_d) if want_device else out_h
 
 
 def restore_frames_sinsr(frames: List[np.ndarray], downscale_maps: np.ndarray, block_size: int, device,

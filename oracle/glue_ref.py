@@ -233,7 +233,10 @@ def blend_by_map(orig: np.ndarray, rest: np.ndarray, dmap: np.ndarray, block_siz
     """utils.py:1581-1599 - mask=(NEAREST-upsampled map>0); fp32 blend; clip; TRUNCATE to u8."""
     h, w = orig.shape[:2]
     by, bx = h // block_size, w // block_size
-    assert dmap.shape == (by, bx), "map/grid mismatch (the reference NEAREST-resizes; not restated)"
+    if dmap.shape != (by, bx):   # utils.py:1586-1587: INTER_NEAREST resize of the map to the block grid
+        ys0 = np.arange(by) * dmap.shape[0] // by
+        xs0 = np.arange(bx) * dmap.shape[1] // bx
+        dmap = dmap[ys0][:, xs0]
     # INTER_NEAREST to (w,h): dst x -> floor(x * bx / w)
     ys = (np.arange(h) * by // h).clip(0, by - 1)
     xs = (np.arange(w) * bx // w).clip(0, bx - 1)

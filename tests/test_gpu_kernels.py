@@ -101,6 +101,8 @@ def test_conv_concat_residual_act_prologue(gpu_device, dtype):
     (3, 0, 64, 9, 33, False),         # cin < one K chunk
     (128, 0, 3, 21, 40, False),       # conv_out-style: 16-channel output tile, cout = 3
     (64, 0, 32, 17, 35, False),       # 32-channel output tile
+    (128, 0, 128, 64, 1920, False),   # the dominant instantiation at full 1080p width: XCD remap, 60 tiles per row
+    (64, 0, 64, 72, 1920, False),     # >= 128 K pixels per image: the 16-row ("tall") 64-channel tile
 ])
 def test_conv_halo_fused(gpu_device, dtype, cfg):
     """The halo kernel with everything fused: GN-affine+SiLU prologue, bias, residual, and the

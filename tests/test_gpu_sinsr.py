@@ -162,3 +162,74 @@ def test_restore_frames_sinsr_surface(gpu_device):
     b = restore.restore_frames_sinsr(frames[1:], maps[1:], 8, gpu_device, cfg=cfg, first_frame_index=1)
     for x, y in zip(a + b, out):
         assert np.array_equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Full-width config in the BENCHMARKED mode (f16 storage + f16 MFMA operands, fused GroupNorm, the VQ lookup
+# on) and in the cheapest mode that meets the north star's 1e-3 bar.  What the f16 mode can and cannot meet is
+# measured, not assumed: tools/precision_study.py emulates every rounding on the CPU (f16 operands ALONE give
+# 1.6e-3, f16 storage alone 1.7e-3, each section alone 0.4 - 1.5e-3), tools/precision_gpu.py measures the modes
+# on the device.  The bounds below are the measured values with ~1.5x head-room, so a precision
+# regression of the fast path fails here.
+def _full_width_case(dev, quantize):
+    from elvis_amd.synth import synth_clip
+    from elvis_amd.weights import SinSRConfig, frame_noise, make_sinsr_weights
+    from oracle import sinsr_ref as R
+    cfg = dataclasses.replace(SinSRConfig(), quantize=quantize)
+    sd = make_sinsr_weights(cfg, 0)
+    lr = torch.from_numpy(synth_clip(20260501, 1, 64, 64)[0])      # the parity tile bench.py reports
+    noise = frame_noise(cfg, 42, 0, 64, 64)
+    ref, stages = R.sinsr_forward(sd, cfg, lr, noise, return_stages=True)
+    return cfg, sd, lr, noise, ref, stages
+
+
+def test_full_width_f16_benchmarked_mode_continuous(gpu_device):
+    from elvis_amd.sinsr import SinSRModel
+    from oracle import sinsr_ref as R
+    cfg, sd, lr, noise, ref, _ = _full_width_case(gpu_device, quantize=False)
+    model = SinSRModel(cfg, sd, gpu_device, torch.float16)           # fuse_gn=True: the default product path
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)
+    d = (f32[0].cpu() - ref).abs()
+    print(f"full-width f16: max-abs {d.max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e}")
+    assert d.max().item() <= 3.5e-3          # measured 2.27e-3; the 1e-3 bar is out of reach for f16 operands
+    assert d.pow(2).mean().sqrt().item() <= 5e-4      # measured 3.3e-4
+    ref_u8, got_u8 = R.to_u8(ref).numpy(), u8[0].cpu().numpy()
+    assert np.abs(got_u8.astype(int) - ref_u8.astype(int)).max() <= 1
+    assert _psnr(got_u8, ref_u8) >= 58.0     # measured 60.0 dB
+    again = model.forward(lr[None].to(gpu_device), noise.to(gpu_device))
+    assert torch.equal(again, u8)            # bit-reproducible
+
+
+def test_full_width_f16_benchmarked_mode_with_vq_lookup(gpu_device):
+    """quantize=True (what bench.py times): the nearest-code lookup is discontinuous, so a latent within f16
+    rounding of a Voronoi boundary picks the neighbouring code.  Asserted: how many codes agree with the fp32
+    oracle's, and the PSNR of the frame that results."""
+    from elvis_amd.sinsr import SinSRModel
+    from oracle import sinsr_ref as R
+    cfg, sd, lr, noise, ref, stages = _full_width_case(gpu_device, quantize=True)
+    model = SinSRModel(cfg, sd, gpu_device, torch.float16)
+    st = {}
+    u8 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), stages=st)
+    _, ref_idx = R.vq_quantize(sd, stages["z0"])
+    _, idx = model.decode(st["z0"], want_idx=True)
+    agree = (idx.cpu().long() == ref_idx).float().mean().item()
+    psnr = _psnr(u8[0].cpu().numpy(), R.to_u8(ref).numpy())
+    print(f"full-width f16 + VQ: code agreement {agree:.4f}, PSNR vs oracle {psnr:.2f} dB")
+    assert agree >= 0.97
+    assert psnr >= 44.0                       # measured 47.3 dB
+
+
+def test_full_width_mixed_mode_meets_the_1e3_bar(gpu_device):
+    """The cheapest measured mode inside the north star's tolerance: the 1080p-resolution decoder level in f16,
+    everything else in exact fp32 MFMA (precision="mixed")."""
+    from elvis_amd.sinsr import SinSRModel
+    from oracle import sinsr_ref as R
+    cfg, sd, lr, noise, ref, _ = _full_width_case(gpu_device, quantize=False)
+    model = SinSRModel(cfg, sd, gpu_device, torch.float16, precision="mixed")
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)
+    err = (f32[0].cpu() - ref).abs().max().item()
+    print("full-width mixed max-abs", err)
+    assert err <= 1e-3                        # measured 7.9e-4
+    ref_u8, got_u8 = R.to_u8(ref).numpy(), u8[0].cpu().numpy()
+    assert np.abs(got_u8.astype(int) - ref_u8.astype(int)).max() <= 1
+    assert _psnr(got_u8, ref_u8) >= 62.0

@@ -1,0 +1,202 @@
+"""GPU tests of the product surfaces that had none: P1 `get_sinsr_upsample_fn`, P3 `restore_with_sinsr_naive`
+under the tiler, `blended_restoration` (floored grid, resized map), pool threads, the directory drivers and
+the per-section mixed precision."""
+import dataclasses
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n, h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.random((n, h // 4 + 1, w // 4 + 1, 3)).astype(np.float32)
+    up = np.kron(base, np.ones((1, 4, 4, 1), np.float32))[:, :h, :w]
+    return [np.round(np.clip(f + rng.normal(0, 0.02, f.shape), 0, 1) * 255).astype(np.uint8) for f in up]
+
+
+def test_p1_upsample_fn_drives_the_reference_loop(gpu_device):
+    """P1 (elvis.py:2528, 2575): the 2x callable plugged into the ORACLE's restatement of
+    upscale_realesrgan_adaptive gives exactly what the on-device staged loop gives."""
+    from elvis_amd import restore
+    from elvis_amd.weights import tiny_config
+    from oracle import glue_ref
+    cfg = tiny_config()
+    frame = _frames(1, 64, 96, 3)[0]
+    lv = np.random.default_rng(4).integers(0, 3, size=(8, 12)).astype(np.int32)
+    up2 = restore.get_sinsr_upsample_fn(gpu_device, scale=2, fp32=True, cfg=cfg)
+    small = up2(np.ascontiguousarray(frame[:16, :24]))
+    assert small.shape == (32, 48, 3) and small.dtype == np.uint8
+    assert restore.get_sinsr_upsample_fn(gpu_device, scale=4, fp32=True, cfg=cfg)(frame[:16, :24].copy()).shape == (64, 96, 3)
+    with pytest.raises(ValueError):
+        restore.get_sinsr_upsample_fn(gpu_device, scale=3)
+    ref = glue_ref.upscale_adaptive(frame, lv, 8, up2, step=2)
+    got = restore.restore_frames_sinsr([frame], lv[None], 8, gpu_device, fp32=True, cfg=cfg, schedule="staged", staged_2x=True)[0]
+    assert np.array_equal(got, ref)
+
+
+def test_p3_naive_restore_under_the_tiler(gpu_device):
+    """P3 (utils.py:1428 signature): resolution-preserving restore_fn, called tile by tile by
+    resource_aware_restore; product tiler (HIP accumulate) == numpy tiler, bit for bit."""
+    import functools
+    from elvis_amd import restore, tiler
+    from elvis_amd.weights import tiny_config
+    from oracle import glue_ref
+    fn = functools.partial(restore.restore_with_sinsr_naive, cfg=tiny_config(), fp32=True)
+    frames = _frames(3, 64, 96, 5)
+    whole = fn(frames=frames, device="cuda:0", some_unknown_kwarg=1)          # unknown kwargs are ignored
+    assert len(whole) == 3 and whole[0].shape == (64, 96, 3)
+    assert fn(frames=[], device="cuda") == []
+    kw = dict(tile_size=32, halo=8, chunk_size=2, chunk_overlap=1, device="cuda:0")
+    got = tiler.resource_aware_restore(fn, frames, **kw)
+    ref = glue_ref.resource_aware_restore(fn, frames, **kw)
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    # gated: a clean map skips the restorer entirely (identity through the tiler is within 1 LSB)
+    gate = functools.partial(tiler.adaptive_restore, fn, degradation_maps=np.zeros((3, 4, 6), np.int32), block_size=16)
+    skipped = tiler.resource_aware_restore(gate, frames, **kw)
+    assert max(int(np.abs(a.astype(int) - b.astype(int)).max()) for a, b in zip(skipped, frames)) <= 1
+
+
+@pytest.mark.parametrize("shape,block,map_shape", [((2, 64, 96), 16, None), ((1, 1080, 1920), 16, None),
+                                                   ((2, 50, 70), 16, None), ((2, 64, 96), 16, (7, 5))])
+def test_blended_restoration(gpu_device, shape, block, map_shape):
+    """utils.py:1575-1601 through the product wrapper: floored block grid (1080 / 16 leaves 8 rows that take
+    the nearest map row), and a map of another shape NEAREST-resized to the grid."""
+    from elvis_amd import tiler
+    from oracle import glue_ref
+    n, h, w = shape
+    rng = np.random.default_rng(6)
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
+    grid = map_shape or (h // block, w // block)
+    maps = rng.integers(0, 3, size=(n,) + grid).astype(np.int32)
+    invert = lambda frames, device=None, **kw: [255 - f for f in frames]
+    for alpha in (1.0, 0.35):
+        got = tiler.blended_restoration(frames, maps, block, alpha=alpha, restore_fn=invert, device="cuda:0",
+                                        tile_size=512, halo=16, chunk_size=0)
+        rest = glue_ref.resource_aware_restore(invert, frames, tile_size=512, halo=16, chunk_size=0, device="cpu")
+        for i in range(n):
+            assert np.array_equal(got[i], glue_ref.blend_by_map(frames[i], rest[i], maps[i], block, alpha))
+
+
+def test_pool_threads_on_one_device(gpu_device):
+    """P2 is called from ThreadPoolExecutor workers (elvis.py:342-346): two threads restoring on the same GPU
+    at once give what serial calls give (per-device handle cache under a lock, per-device kernel attributes)."""
+    from elvis_amd import parallel_process_frames, restore
+    from elvis_amd.weights import tiny_config
+    cfg = tiny_config()
+    frames = _frames(4, 64, 96, 7)
+    maps = np.random.default_rng(8).integers(0, 3, size=(4, 8, 12)).astype(np.int32)
+    serial = restore.restore_frames_sinsr(frames, maps, 8, gpu_device, cfg=cfg)
+    out = [None, None]
+
+    def work(k):
+        sl = slice(2 * k, 2 * k + 2)
+        out[k] = restore.restore_frames_sinsr(frames[sl], maps[sl], 8, "cuda:0", cfg=cfg, first_frame_index=2 * k)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(np.array_equal(a, b) for a, b in zip(out[0] + out[1], serial))
+    # and through the reference's own thread-pool helper, chunk_size forcing two chunks on the one device
+    state = {"i": 0}
+
+    def process_fn(chunk, device):
+        first = next(i for i, f in enumerate(frames) if f is chunk[0])
+        return restore.restore_frames_sinsr(chunk, maps[first:first + len(chunk)], 8, device, cfg=cfg, first_frame_index=first)
+
+    pooled = parallel_process_frames(process_fn, frames, [torch.device("cuda:0")], chunk_size=2, max_workers=2)
+    assert all(np.array_equal(a, b) for a, b in zip(pooled, serial))
+
+
+def test_directory_drivers_match_frames_level(gpu_device, tmp_path):
+    from elvis_amd import drivers, frameio, restore
+    from elvis_amd.weights import tiny_config
+    cfg = tiny_config()
+    frames = _frames(3, 64, 96, 9)
+    rng = np.random.default_rng(10)
+    src, dst = tmp_path / "in", tmp_path / "out"
+    for i, f in enumerate(frames):
+        frameio.save_frame(f, src / f"{i + 1:05d}.png")
+    lv = rng.integers(0, 3, size=(3, 8, 12)).astype(np.uint8)
+    drivers.restore_downsampled_with_sinsr(str(src), str(dst), lv, 8, devices=[0], cfg=cfg, tile=0, model_name="x")
+    want = restore.restore_frames_sinsr(frames, lv, 8, gpu_device, cfg=cfg)
+    assert [p.name for p in frameio.get_frame_paths(dst)] == [f"{i + 1:05d}.png" for i in range(3)]
+    assert all(np.array_equal(frameio.load_frame(dst / f"{i + 1:05d}.png"), want[i]) for i in range(3))
+    # Blur and DCT: in place
+    rounds = rng.integers(0, 3, size=(3, 8, 12)).astype(np.int32)
+    want_b = restore.restore_frames_blur(frames, rounds, 8, gpu_device, batch_size=2)
+    drivers.restore_blur_adaptive(str(src), rounds, 8, devices=["cuda:0"], batch_size=2)
+    got_b = frameio.load_frames(src)
+    assert all(np.array_equal(a, b) for a, b in zip(got_b, want_b))
+    for i, f in enumerate(frames):
+        frameio.save_frame(f, src / f"{i + 1:05d}.png")
+    want_d = restore.restore_frames_dct(frames, rounds, 8, gpu_device)
+    drivers.restore_dct_adaptive(str(src), rounds, 8, devices=["cuda:0"])
+    assert all(np.array_equal(a, b) for a, b in zip(frameio.load_frames(src), want_d))
+
+
+def test_convert_act_and_mixed_sections(gpu_device):
+    from elvis_amd import ops
+    from elvis_amd.sinsr import SinSRModel
+    from elvis_amd.weights import tiny_config
+    x = torch.randn(2, 5, 7, 16, device=gpu_device)
+    a = ops.Act(x.clone(), 13, stats=torch.ones(1, device=gpu_device))
+    h = ops.convert_act(a, torch.float16)
+    assert h.t.dtype == torch.float16 and h.stats is None and torch.equal(h.t, x.half())
+    f = ops.convert_act(ops.Act(h.t, 13, stats=a.stats), torch.float32)
+    assert f.t.dtype == torch.float32 and f.stats is a.stats and torch.equal(f.t, x.half().float())
+    assert ops.convert_act(a, torch.float32) is a
+    with pytest.raises(ValueError):
+        SinSRModel(tiny_config(), None, gpu_device, precision="mixed:nope")
+    conv = ops.PackedConv(torch.randn(8, 13, 3, 3), None, torch.float16, gpu_device, 13)
+    with pytest.raises(ValueError, match="packed for"):
+        conv(a)
+
+
+def test_mixed_precision_sits_between_f16_and_f32(gpu_device):
+    """precision="mixed:<sections>" runs the listed sections in f16 and the rest in exact fp32; on the narrow
+    config every choice stays inside the fp32 bar's order of magnitude and all-f16 sections == the f16 mode."""
+    from elvis_amd.sinsr import SinSRModel
+    from elvis_amd.weights import frame_noise, make_sinsr_weights, tiny_config
+    from oracle import sinsr_ref as R
+    cfg = dataclasses.replace(tiny_config(), quantize=False)
+    sd = make_sinsr_weights(cfg, 0)
+    lr = torch.from_numpy(_frames(1, 32, 48, 11)[0])
+    noise = frame_noise(cfg, 42, 0, *R.padded_latent_shape(cfg, 32, 48))
+    ref = R.sinsr_forward(sd, cfg, lr, noise)
+
+    def err(**kw):
+        m = SinSRModel(cfg, sd, gpu_device, kw.pop("dtype", torch.float16), **kw)
+        return (m.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)[1][0].cpu() - ref).abs().max().item()
+
+    e32, e16 = err(dtype=torch.float32), err()
+    e_mixed = err(precision="mixed:dec0")
+    e_all = err(precision="mixed:" + "+".join(SinSRModel.SECTIONS))
+    assert e32 < 1e-4 and e_mixed < 1e-3 and e_mixed < e16 and e_all == pytest.approx(e16, rel=0.5)
+
+
+def test_host_to_host_pipeline_equals_device_path(gpu_device):
+    """restore_clip_single4x_host (pinned host in/out, copy streams, threaded noise generator) restores exactly
+    what the HBM-resident function restores, also when called twice in a row (staging buffers are reused)."""
+    from elvis_amd import restore
+    from elvis_amd.weights import tiny_config
+    model = restore.get_sinsr_model(gpu_device, cfg=tiny_config())
+    frames = np.stack(_frames(5, 64, 96, 21))
+    lv = np.random.default_rng(22).integers(0, 3, size=(5, 8, 12)).astype(np.int32)
+    lv[3] = 0
+    fh, lh = torch.from_numpy(frames).pin_memory(), torch.from_numpy(lv).pin_memory()
+    gidx = [40 + i for i in range(5)]
+    want = restore.restore_clip_single4x_device(model, fh.to(gpu_device), lh.to(gpu_device), 8, gidx, batch=2).cpu()
+    out = torch.empty_like(fh).pin_memory()
+    for _ in range(2):
+        out.zero_()
+        got, dev_buf = restore.restore_clip_single4x_host(model, fh, lh, 8, gidx, out, batch=2, want_device=True)
+        torch.cuda.synchronize()
+        assert got is out and torch.equal(out, want) and torch.equal(dev_buf.cpu(), want)
+    assert torch.equal(out[3], fh[3])
+    with pytest.raises(ValueError):
+        restore.restore_clip_single4x_host(model, fh.to(gpu_device), lh, 8, gidx)
