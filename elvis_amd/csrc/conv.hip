@@ -50,6 +50,7 @@ struct ConvArgs {
     int sub, par_a, par_b;   // 2x2 modes (KS == 2): output pixel (ostr*y + par_a, ostr*x + par_b)
     int ostr, pad2y, pad2x;  // sub-pixel: ostr 2, pad 1 - par; space-to-depth stride-2 form: ostr 1, pad 0
     int s2d, istr, nkc_c, wfull;   // s2d: K chunk kc = phase (kc / nkc_c) of the full-res input (row stride wfull), istr = 2
+    int strip;            // > 0: pixel tiles are walked in column strips of this many tiles (L2 reuse of halo rows)
 };
 
 template <typename T> struct Frag;
@@ -482,10 +483,28 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const int co_tile = (int)(bid % p.n_co_tiles);
     long long t = bid / p.n_co_tiles;
 #endif
-    const int tx = (int)(t % p.tiles_x);
-    t /= p.tiles_x;
-    const int ty = (int)(t % p.tiles_y);
-    const int nimg = (int)(t / p.tiles_y);
+    // Pixel-tile walk.  Row-major over the full image width puts vertical neighbours tiles_x tiles apart; column
+    // strips of `strip` tiles, walked top to bottom, bring the two tiles that share halo rows `strip` tiles apart,
+    // inside the set of workgroups resident on the XCD.  (Measured: no change in kernel time on any hot shape -
+    // the halo re-reads are served by L2 / the Infinity Cache either way; kept for its lower fabric traffic.)
+    int tx, ty, nimg;
+    if (p.strip > 0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        nimg = (int)(t / per_img);
+        int r = (int)(t - (long long)nimg * per_img);
+        const int full = p.tiles_x / p.strip, strip_tiles = p.strip * p.tiles_y;
+        int s = r / strip_tiles;
+        int sw = p.strip;
+        if (s >= full) { s = full; sw = p.tiles_x - full * p.strip; }
+        r -= s * strip_tiles;
+        ty = r / sw;
+        tx = s * p.strip + (r - ty * sw);
+    } else {
+        tx = (int)(t % p.tiles_x);
+        t /= p.tiles_x;
+        ty = (int)(t % p.tiles_y);
+        nimg = (int)(t / p.tiles_y);
+    }
     const int oy0 = ty * TY, ox0 = tx * TX, co0 = co_tile * TCO;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1607,6 +1626,11 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
         a.w_in = d->wo;
     }
     a.tiles_x = ((subpix ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
+    {
+        const char* e = getenv("ELVIS_STRIP");   // A/B switch (read per call); 0 = row-major walk
+        a.strip = e ? atoi(e) : 8;
+        if (a.strip < 0 || a.strip >= a.tiles_x) a.strip = 0;
+    }
     const int tyv = halo_ty(d);
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;

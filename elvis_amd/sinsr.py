@@ -88,7 +88,8 @@ class _ResBlock:
     # The fused prologue recomputes normalise+SiLU once per 128-channel output tile (and 1.33x for
     # the halo); with >= 4 output tiles it is cheaper to materialise the activated tensor once
     # (one extra read+write) and run the faster prologue-free 16x32-tile kernel.
-    FUSE_MAX_COUT = 1 << 30   # measured: materialising was NOT faster end to end (13.9 vs 14.6 fps)
+    import os as _os
+    FUSE_MAX_COUT = int(_os.environ.get("ELVIS_FUSE_MAX_COUT", str(1 << 30)))   # A/B switch, see DESIGN.md 5.2
 
     def __call__(self, x: Act, x2: Optional[Act] = None, fuse_gn=False) -> Act:
         xs = [x] if x2 is None else [x, x2]
