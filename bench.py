@@ -261,7 +261,8 @@ def slot_run(kind, dev, mode, frames=6):
     torch.cuda.empty_cache()
     return {"workload": f"{frames}-frame 1920x1080 clip, ELVIS v2 {'DCT (DCNv2 restorer)' if kind == 'dct' else 'Blur (Swin deblur, 1 round)'}, HBM-resident",
             "frames_per_s": frames / el, "dominant_kernel": cands[0][1] if cands else None,
-            "second_kernel": cands[1][1] if len(cands) > 1 else None}
+            "second_kernel": cands[1][1] if len(cands) > 1 else None,
+            "other_kernels": [c[1] for c in cands[2:5]]}
 
 
 # ----------------------------------------------------------------------------- one rank

@@ -22,6 +22,9 @@ SOURCES = ["api.hip", "glue.hip", "misc.hip", "norm.hip", "attn.hip", "dcn.hip",
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
          "-ffp-contract=off"]  # bit-exact glue: no implicit FMA contraction (explicit fmaf where wanted)
+# per-source extras: the tiled DCNv2 kernel fully unrolls its 64 (group, tap) samples so that every register
+# index is static - beyond clang's default size limit for `#pragma unroll`
+EXTRA_FLAGS = {"dcn.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
 
 
 def _hipcc() -> str:
@@ -52,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")

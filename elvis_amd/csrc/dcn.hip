@@ -6,11 +6,21 @@
 //
 // with offsets laid out channel = (g*9 + k)*2 + {0: dy, 1: dx}, masks channel = g*9 + k (already
 // passed through the sigmoid by the caller's choice: `mask_sigmoid`), zero contribution from
-// out-of-image corners.  Phase 1 gathers the K = cin*9 modulated samples of 64 pixels into an LDS
-// im2col tile (irregular, L1/L2-served 2-byte taps) - the HBM/gather-bound part; phase 2 is the
-// small [64 px] x [K = cin*9] x [cout] product in fp32 FMAs (K = 63 for the 7-frame restorer: too
-// thin to be worth an MFMA pipeline; moving it to the matrix cores is listed as next in DESIGN.md).
+// out-of-image corners.
+//
+// Two kernels:
+//  * dcnv2_tile_kernel (f16, one channel per deformable group, cin <= 8, cout <= 64 - the restorer's shape):
+//    a workgroup owns an 8 x 32 pixel tile; the input window (tile + 8 pixels of halo) sits in LDS as fp32
+//    planes, so the four bilinear corners of a tap are two ds_read2_b32 (offsets are bounded in practice;
+//    a corner outside the window falls back to a bounds-checked global read); a thread reads its pixel's
+//    offset/mask row with 16-byte loads, applies the sigmoid once per (group, tap), and packs the K = 9*cin
+//    modulated samples (K 63 -> 64) as f16 into a swizzled [pixel][32 k] LDS image; phase 2 is
+//    [64 cout] x [K] x [64 px] per wave on v_mfma_f32_16x16x32_f16 with fp32 accumulation, bias + ReLU and
+//    32-byte-per-lane NHWC stores.  HBM-bound by design: 378 B of offsets/masks in, 128 B out per pixel.
+//  * dcnv2_kernel (any dtype / grouping): the generic scalar form - the fp32 exact mode and odd shapes.
 #include "common.h"
+#include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -80,6 +90,164 @@ __global__ __launch_bounds__(256) void dcnv2_kernel(const T* __restrict__ x, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TY_ = 8, TX_ = 32, RH = 8;                     // tile, halo radius of the LDS input window
+constexpr int WY_ = TY_ + 2 * RH, WX_ = TX_ + 2 * RH;        // 24 x 48 window
+constexpr int WP_ = WY_ * WX_;
+constexpr int XIN_BYTES = 8 * WP_ * 4;                       // fp32 planes [8][WY_][WX_]
+constexpr int IMG_BYTES = 64 * 64;                           // one [64 rows][32 k] f16 image (rows = cout or pixels)
+
+__device__ __forceinline__ int img_off(int row, int q) {     // 64-byte rows, 16-byte chunk q, XOR swizzle (as conv.hip)
+    return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4);
+}
+
+template <int CIN>   // compile-time: the mask halfs start at 18*CIN and every register index below must be static
+__global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __restrict__ x, const half_t* __restrict__ om,
+                                                             const half_t* __restrict__ wt, const float* __restrict__ bias,
+                                                             half_t* __restrict__ out, int n, int h, int w,
+                                                             int x_pitch, int om_pitch, int mask_sigmoid, int cout,
+                                                             int out_pitch, int act, int tiles_x, int tiles_y) {
+    constexpr int cin = CIN, ksteps = (CIN * 9 + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const xin = reinterpret_cast<float*>(smem_raw);
+    char* const wimg = smem_raw + XIN_BYTES;                               // [ksteps] images of the weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* const col = wimg + ksteps * IMG_BYTES + wave * ksteps * IMG_BYTES;   // this wave's [ksteps] images of samples
+    constexpr int K = cin * 9;
+
+    int t = blockIdx.x;
+    const int txi = t % tiles_x; t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int ni = t / tiles_y;
+    const int y00 = tyi * TY_ - RH, x00 = txi * TX_ - RH;                  // image coordinates of window (0, 0)
+    const half_t* const xb = x + (long long)ni * h * w * x_pitch;
+
+    // ---- stage the input window (zero outside the image) and the weights (rows permuted so that a lane ends up
+    //      with 16 contiguous output channels: image row fi*16 + 4q + r holds channel 16q + 4fi + r)
+    for (int i = tid; i < WP_; i += 256) {
+        const int wy = i / WX_, wx = i - wy * WX_;
+        const int gy = y00 + wy, gx = x00 + wx;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const uint4*>(xb + ((long long)gy * w + gx) * x_pitch);
+        const half8 hv = __builtin_bit_cast(half8, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xin[c * WP_ + i] = (float)hv[c];
+    }
+    for (int i = tid; i < ksteps * IMG_BYTES / 4; i += 256) reinterpret_cast<unsigned*>(wimg)[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < cout * K; i += 256) {
+        const int co = i / K, k = i - co * K;
+        const int row = ((co & 15) >> 2) * 16 + (co >> 4) * 4 + (co & 3);
+        *reinterpret_cast<half_t*>(wimg + (k >> 5) * IMG_BYTES + img_off(row, (k & 31) >> 3) + (k & 7) * 2) = wt[i];
+    }
+
+    // ---- phase 1: one pixel per thread
+    const int ty = tid >> 5, tx = tid & 31;                                // wave w owns tile rows 2w, 2w + 1
+    const int gy = tyi * TY_ + ty, gx = txi * TX_ + tx;
+    const bool pok = gy < h && gx < w;
+    const long long pix = ((long long)ni * h + (pok ? gy : 0)) * w + (pok ? gx : 0);
+    unsigned omw[96];                                                      // the pixel's 189 offset / mask halfs
+    {
+        const uint4* op = reinterpret_cast<const uint4*>(om + pix * om_pitch);
+        constexpr int n16 = (27 * cin * 2 + 15) / 16;                      // 16-byte pieces that hold them
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < n16) v = op[i];
+            omw[4 * i] = v.x; omw[4 * i + 1] = v.y; omw[4 * i + 2] = v.z; omw[4 * i + 3] = v.w;
+        }
+    }
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    constexpr int mask_h0 = 18 * cin;                                      // first mask half
+    unsigned pk[4];                                                        // eight packed samples
+    const int prow = lane;                                                 // this pixel's row in the wave's images
+#pragma unroll
+    for (int kk = 0; kk < ksteps * 32; ++kk) {                             // k = g*9 + tap (one channel per group)
+        const int g = kk / 9, tap = kk - g * 9;
+        float v = 0.f;
+        if (kk < K) {
+            const half2v d = __builtin_bit_cast(half2v, omw[kk]);          // (dy, dx) = halfs 2kk, 2kk + 1
+            const int mh = mask_h0 + kk;
+            const half2v mm = __builtin_bit_cast(half2v, omw[(mh >> 1) < 96 ? (mh >> 1) : 0]);   // static index
+            float m = (float)mm[mh & 1];
+            if (mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
+            const float sy = (float)(gy + tap / 3 - 1) + (float)d[0], sx = (float)(gx + tap % 3 - 1) + (float)d[1];
+            const float fy = floorf(sy), fx = floorf(sx);
+            const float ly = sy - fy, lx = sx - fx;
+            // clamp far-away samples (they contribute zero anyway) so the int conversion cannot overflow
+            const int y0 = (int)fminf(fmaxf(fy, -4.0f), (float)h + 2.0f), x0 = (int)fminf(fmaxf(fx, -4.0f), (float)w + 2.0f);
+            const int wy = y0 - y00, wx = x0 - x00;
+            float v00, v01, v10, v11;
+            if (wy >= 0 && wy < WY_ - 1 && wx >= 0 && wx < WX_ - 1) {      // all four corners inside the LDS window
+                const float* c0 = xin + g * WP_ + wy * WX_ + wx;
+                v00 = c0[0]; v01 = c0[1]; v10 = c0[WX_]; v11 = c0[WX_ + 1];
+            } else {                                                       // rare: bounds-checked global reads
+                auto tapg = [&](int yy, int xx) -> float {
+                    return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (float)xb[((long long)yy * w + xx) * x_pitch + g] : 0.f;
+                };
+                v00 = tapg(y0, x0); v01 = tapg(y0, x0 + 1); v10 = tapg(y0 + 1, x0); v11 = tapg(y0 + 1, x0 + 1);
+            }
+            v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            v *= m;
+            if (!pok) v = 0.f;
+        }
+        {   // pack two samples per dword, store eight per 16-byte chunk
+            const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (half_t)v);
+            if ((kk & 1) == 0) pk[(kk & 7) >> 1] = hb; else pk[(kk & 7) >> 1] |= hb << 16;
+            if ((kk & 7) == 7 && (kk >> 5) < ksteps)
+                *reinterpret_cast<uint4*>(col + (kk >> 5) * IMG_BYTES + img_off(prow, (kk & 31) >> 3)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+    __syncthreads();   // weights image complete (written by all threads); the wave's own samples are ordered by lgkmcnt
+
+    // ---- phase 2: this wave's 64 pixels x 64 output channels on the matrix cores
+    const int lq = lane >> 4, lr = lane & 15;
+    float4v acc[4][4];
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = lq * 16 + fi * 4 + r;
+            const float b = (bias && co < cout) ? bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[fi][j][r] = b;
+        }
+    for (int s = 0; s < ksteps; ++s) {
+        half8 fa[4], fb[4];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) fa[fi] = *reinterpret_cast<const half8*>(wimg + s * IMG_BYTES + img_off(fi * 16 + lr, lq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const half8*>(col + s * IMG_BYTES + img_off(j * 16 + lr, lq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc[fi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fi], fb[j], acc[fi][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pl = wave * 64 + j * 16 + lr;                            // pixel of the tile (row-major 8 x 32)
+        const int oy = tyi * TY_ + (pl >> 5), ox = txi * TX_ + (pl & 31);
+        if (oy >= h || ox >= w) continue;
+        half_t* op = out + (((long long)ni * h + oy) * w + ox) * out_pitch + lq * 16;
+        half_t o[16];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[fi][j][r];
+                if (act == 3) v = fmaxf(v, 0.f);
+                o[fi * 4 + r] = (half_t)v;
+            }
+        if (lq * 16 + 16 <= cout && (out_pitch & 7) == 0) {
+            *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(o);
+            *reinterpret_cast<uint4*>(op + 8) = *reinterpret_cast<const uint4*>(o + 8);
+        } else {
+            for (int e = 0; e < 16; ++e)
+                if (lq * 16 + e < cout) op[e] = o[e];
+        }
+    }
+}
+
 // frames u8 [F,H,W,3] -> float planes [(f*3 + c), H, W, pitch]: channel t of plane (f,c) is colour c
 // of frame clamp(f + t - radius, 0, F-1), scaled to [0,1].
 template <typename T>
@@ -140,6 +308,42 @@ extern "C" int elvis_dcnv2(const void* x, const void* offset_mask, const void* w
     const long long total = (long long)n * h * w;
     const unsigned grid = (unsigned)((total + DPX - 1) / DPX);
     const int mask_off = deformable_groups * 18;
+    // the tiled gather + MFMA kernel: f16, one channel per deformable group, up to 8 channels, up to 64 outputs
+    static const bool no_tile = getenv("ELVIS_DCN_GENERIC") != nullptr;   // A/B switch
+    if (dtype == ELVIS_F16 && !no_tile && deformable_groups == cin && (cin == 7 || cin == 8) && x_pitch == 8 && cout <= 64 &&
+        om_pitch % 8 == 0 && (((uintptr_t)x | (uintptr_t)offset_mask | (uintptr_t)out) & 15) == 0) {
+        const int ksteps = (K + 31) / 32;
+        const int tiles_x = (w + TX_ - 1) / TX_, tiles_y = (h + TY_ - 1) / TY_;
+        const size_t lds2 = XIN_BYTES + (size_t)ksteps * IMG_BYTES * 5;
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        {
+            std::lock_guard<std::mutex> guard(mu);
+            if (!attr_set[dev]) {
+                hipError_t e = hipFuncSetAttribute((const void*)dcnv2_tile_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute((const void*)dcnv2_tile_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) {
+                    elvis_set_error("elvis_dcnv2: cannot reserve LDS: %s", hipGetErrorString(e));
+                    return ELVIS_E_RUNTIME;
+                }
+                attr_set[dev] = true;
+            }
+        }
+        ELVIS_REQUIRE((long long)n * tiles_x * tiles_y < 0x7fffffffLL, "elvis_dcnv2: grid too large");
+        if (cin == 7)
+            hipLaunchKernelGGL(dcnv2_tile_kernel<7>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), lds2, (hipStream_t)stream,
+                               (const half_t*)x, (const half_t*)offset_mask, (const half_t*)weight, bias, (half_t*)out, n, h, w,
+                               x_pitch, om_pitch, mask_sigmoid, cout, out_pitch, act, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(dcnv2_tile_kernel<8>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), lds2, (hipStream_t)stream,
+                               (const half_t*)x, (const half_t*)offset_mask, (const half_t*)weight, bias, (half_t*)out, n, h, w,
+                               x_pitch, om_pitch, mask_sigmoid, cout, out_pitch, act, tiles_x, tiles_y);
+        ELVIS_CHECK_LAUNCH("elvis_dcnv2(tile)");
+        return ELVIS_OK;
+    }
     if (dtype == ELVIS_F16)
         hipLaunchKernelGGL(dcnv2_kernel<half_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const half_t*)x,
                            (const half_t*)offset_mask, (const half_t*)weight, bias, (half_t*)out, n, h, w, cin, x_pitch,
