@@ -303,8 +303,13 @@ def main():
     model = restore.get_sinsr_model(dev, cfg=cfg, fp32=(args.mode == "f32"), fuse_gn=args.fuse_gn)
 
     # ---- synthetic clip (host, untimed): a few distinct frames tiled to F to keep setup short
+    # (clean clip and level maps on the host; the server-side degrade - per block INTER_AREA down by 2**level,
+    # INTER_LINEAR back, elvis.py:2141-2169 - runs on the device: elvis_amd.degrade)
+    from elvis_amd import degrade
     base_frames = min(F, 6)
-    clean, degraded, levels = synth.make_downsample_case(base_frames, H, W, B, max_level=3)
+    clean = synth.synth_clip(synth.CLIP_SEED, base_frames, H, W)
+    levels = np.minimum(synth.synth_level_maps(synth.MAP_SEED, base_frames, H // B, W // B), 3).astype(np.int32)
+    degraded = degrade.degrade_downsample_device(torch.from_numpy(clean).to(dev), torch.from_numpy(levels).to(dev), B).cpu().numpy()
     reps = (F + base_frames - 1) // base_frames
     frames_h = torch.from_numpy(np.concatenate([degraded] * reps)[:F]).pin_memory()
     levels_h = torch.from_numpy(np.concatenate([levels] * reps)[:F].astype(np.int32)).pin_memory()

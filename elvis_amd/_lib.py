@@ -61,6 +61,9 @@ SIGNATURES = {
     "elvis_pad_reflect_axpy": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, f32, vp],
     "elvis_crop_copy": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "elvis_convert_act": [vp, i32, vp, i32, i64, i32, vp],
+    "elvis_degrade_downsample_u8": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "elvis_degrade_gaussian_u8": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, f32, vp],
+    "elvis_degrade_dct_u8": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "elvis_dcnv2": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "elvis_temporal_stack": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "elvis_plane_merge": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

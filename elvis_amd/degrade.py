@@ -1,0 +1,124 @@
+"""Server-side per-block degrade filters on the device - what produces the hot path's
+inputs, so benchmark and test clips are built on the GPU instead of by a python loop over 32 400 blocks.
+
+`filter_frame_downsample` / `filter_frame_gaussian` keep the reference's names, arguments and return values
+(elvis.py:2141-2196: BGR or RGB uint8 HWC image + per-block scores in [0,1] -> (filtered image, int32 map));
+`filter_frame_dct` is the build's definition of the ELVIS v2 DCT degrade (the reference has none).
+The `*_device` forms work on resident `[n,H,W,C]` uint8 tensors and `[n,By,Bx]` int32 maps.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr
+from .ops import _chk_u8, _s
+
+DCT_LEVELS = 4
+_TABLES: Dict[str, tuple] = {}
+
+
+def gaussian_taps() -> Tuple[float, float, float]:
+    """getGaussianKernel(5, 1.0): normalised in float64, rounded to float32; (k0, k1, k2) of (k0 k1 k2 k1 k0)."""
+    k = np.exp(-np.arange(-2, 3, dtype=np.float64) ** 2 / 2.0)
+    k = (k / k.sum()).astype(np.float32)
+    return float(k[0]), float(k[1]), float(k[2])
+
+
+def _dct_tables(device) -> tuple:
+    key = str(device)
+    if key not in _TABLES:
+        u = np.arange(8, dtype=np.float64)[:, None]
+        x = np.arange(8, dtype=np.float64)[None, :]
+        basis = np.cos((2 * x + 1) * u * np.pi / 16.0) * np.sqrt(2.0 / 8.0)
+        basis[0] *= np.sqrt(0.5)
+        uv = (np.arange(8)[:, None] + np.arange(8)[None, :]).astype(np.float64)
+        gain = np.stack([np.exp2(-lv * uv / 14.0) for lv in range(DCT_LEVELS)])
+        _TABLES[key] = (torch.from_numpy(basis.astype(np.float32)).to(device), torch.from_numpy(gain.astype(np.float32)).to(device))
+    return _TABLES[key]
+
+
+def _maps(levels_d: torch.Tensor, n: int) -> torch.Tensor:
+    if levels_d.dtype != torch.int32 or levels_d.dim() != 3 or levels_d.shape[0] != n or not levels_d.is_cuda:
+        raise ValueError("degrade: the map must be a CUDA int32 tensor [n, by, bx]")
+    return levels_d.contiguous()
+
+
+def degrade_downsample_device(frames_d: torch.Tensor, levels_d: torch.Tensor, block_size: int, out=None) -> torch.Tensor:
+    _chk_u8(frames_d)
+    n, h, w, c = frames_d.shape
+    m = _maps(levels_d, n)
+    out = torch.empty_like(frames_d) if out is None else out
+    check(lib().elvis_degrade_downsample_u8(ptr(frames_d), ptr(m), ptr(out), n, h, w, c, block_size, m.shape[1], m.shape[2],
+                                            _s(frames_d)), frames_d.device)
+    return out
+
+
+def degrade_gaussian_device(frames_d: torch.Tensor, rounds_d: torch.Tensor, block_size: int, out=None) -> torch.Tensor:
+    _chk_u8(frames_d)
+    n, h, w, c = frames_d.shape
+    m = _maps(rounds_d, n)
+    out = torch.empty_like(frames_d) if out is None else out
+    k0, k1, k2 = gaussian_taps()
+    check(lib().elvis_degrade_gaussian_u8(ptr(frames_d), ptr(m), ptr(out), n, h, w, c, block_size, m.shape[1], m.shape[2],
+                                          k0, k1, k2, _s(frames_d)), frames_d.device)
+    return out
+
+
+def degrade_dct_device(frames_d: torch.Tensor, levels_d: torch.Tensor, out=None) -> torch.Tensor:
+    _chk_u8(frames_d)
+    n, h, w, c = frames_d.shape
+    m = _maps(levels_d, n)
+    basis, gain = _dct_tables(frames_d.device)
+    out = torch.empty_like(frames_d) if out is None else out
+    check(lib().elvis_degrade_dct_u8(ptr(frames_d), ptr(m), ptr(out), ptr(basis), ptr(gain), DCT_LEVELS, n, h, w, c,
+                                     m.shape[1], m.shape[2], _s(frames_d)), frames_d.device)
+    return out
+
+
+def _one_frame(image: np.ndarray, maps: np.ndarray, device, fn, *args) -> np.ndarray:
+    dev = torch.device("cuda:0" if str(device) == "cuda" else device)
+    L.require_gpu(dev)
+    if image.dtype != np.uint8 or image.ndim != 3:
+        raise ValueError("degrade filters take uint8 (H,W,C) images")
+    with torch.cuda.device(dev):
+        img_d = torch.from_numpy(np.ascontiguousarray(image)[None]).to(dev)
+        map_d = torch.from_numpy(np.ascontiguousarray(maps.astype(np.int32))[None]).to(dev)
+        return fn(img_d, map_d, *args)[0].cpu().numpy()
+
+
+def _check_grid(image: np.ndarray, scores: np.ndarray, block_size: int):
+    h, w = image.shape[:2]
+    if h % block_size or w % block_size:
+        raise ValueError("Image dimensions must be divisible by block_size.")   # split_image_into_blocks, elvis.py:1376
+    if scores.shape != (h // block_size, w // block_size):
+        raise ValueError(f"scores {scores.shape} do not match the block grid {(h // block_size, w // block_size)}")
+
+
+def filter_frame_downsample(image: np.ndarray, frame_scores: np.ndarray, block_size: int, device="cuda:0"):
+    """elvis.py:2141-2169 on the device: levels = round(score * log2(block_size)); every block of level L is
+    INTER_AREA-downscaled by 2**L and INTER_LINEAR-upscaled back.  Returns (image, int32 level map)."""
+    _check_grid(image, frame_scores, block_size)
+    levels = np.round(frame_scores * int(np.log2(block_size))).astype(np.int32)
+    return _one_frame(image, levels, device, degrade_downsample_device, block_size), levels
+
+
+def filter_frame_gaussian(image: np.ndarray, frame_scores: np.ndarray, block_size: int, device="cuda:0"):
+    """elvis.py:2171-2196 on the device: rounds = round(score * 10) passes of GaussianBlur(5x5, sigma 1) per
+    block (BORDER_REFLECT_101 at the block edges).  Returns (image, int32 rounds map)."""
+    _check_grid(image, frame_scores, block_size)
+    rounds = np.round(frame_scores * 10).astype(np.int32)
+    return _one_frame(image, rounds, device, degrade_gaussian_device, block_size), rounds
+
+
+def filter_frame_dct(image: np.ndarray, frame_scores: np.ndarray, block_size: int = 8, device="cuda:0"):
+    """ELVIS v2 DCT degrade (build-defined): levels = round(score * 3); per 8x8 block the
+    DCT coefficient (u,v) is scaled by 2^(-level*(u+v)/14).  Returns (image, int32 level map)."""
+    if block_size != 8:
+        raise ValueError("the DCT degrade works on 8x8 blocks")
+    _check_grid(image, frame_scores, block_size)
+    levels = np.round(frame_scores * (DCT_LEVELS - 1)).astype(np.int32)
+    return _one_frame(image, levels, device, degrade_dct_device), levels

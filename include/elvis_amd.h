@@ -226,6 +226,27 @@ int elvis_crop_copy(const void* x, void* y, int dtype, int n, int h_in, int w_in
 int elvis_convert_act(const void* x, int src_dtype, void* y, int dst_dtype, long long pixels, int pitch,
                       elvis_stream_t stream);
 
+/* ------------------------------------------------------------------ server-side degrade filters
+ * Every block_size x block_size block of a uint8 NHWC frame is filtered as its own image (nothing leaks between
+ * blocks); map[n, by, bx] int32 with by = H / block_size, bx = W / block_size (H, W divisible by block_size). */
+
+/* filter_frame_downsample (elvis.py:2141-2169): per block, INTER_AREA downscale by 2**level then INTER_LINEAR
+ * back to block_size (OpenCV's u8 fixed-point rules restated; block_size a power of two <= 16). */
+int elvis_degrade_downsample_u8(const uint8_t* src, const int32_t* levels, uint8_t* dst, int n, int h, int w, int c,
+                                int block_size, int by, int bx, elvis_stream_t stream);
+
+/* filter_frame_gaussian (elvis.py:2171-2196): per block, `rounds` passes of a separable 5-tap Gaussian with the
+ * symmetric taps (tap0, tap1, tap2, tap1, tap0), BORDER_REFLECT_101 at the block's own edges, float32
+ * arithmetic, round-half-even to uint8 after every pass pair (block_size <= 16). */
+int elvis_degrade_gaussian_u8(const uint8_t* src, const int32_t* rounds, uint8_t* dst, int n, int h, int w, int c,
+                              int block_size, int by, int bx, float tap0, float tap1, float tap2, elvis_stream_t stream);
+
+/* DCT-coefficient dampening (the build's definition of ELVIS v2 DCT's degrade; README.md:44 names it, the reference
+ * holds no code): 8x8 blocks; basis64 = f32[8][8] DCT-II basis, gain = f32[n_levels][8][8] per-level coefficient
+ * gains (both device pointers), level clamped to [0, n_levels). */
+int elvis_degrade_dct_u8(const uint8_t* src, const int32_t* levels, uint8_t* dst, const float* basis64, const float* gain,
+                         int n_levels, int n, int h, int w, int c, int by, int bx, elvis_stream_t stream);
+
 /* ------------------------------------------------------------------ DCT slot (LaplacianVCAR-style) */
 
 /* DCNv2 modulated deformable 3x3 convolution (stride 1, pad 1, dilation 1), NHWC.
