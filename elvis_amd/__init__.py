@@ -15,6 +15,7 @@ from .tiler import (adaptive_restore, blended_restoration, resource_aware_restor
 from .frameio import (clear_directory, decode_strength_maps_from_npz, encode_strength_maps_to_npz,  # noqa: F401
                       get_frame_paths, load_block_masks, load_frame, load_strength_maps, save_block_masks, save_frame)
 from .degrade import filter_frame_dct, filter_frame_downsample, filter_frame_gaussian  # noqa: F401
+from .metrics import calculate_block_ssim, calculate_mse, calculate_psnr, masked_mse, masked_psnr  # noqa: F401
 from .drivers import restore_blur_adaptive, restore_dct_adaptive, restore_downsampled_with_sinsr  # noqa: F401
 from .restore import (get_sinsr_model, get_sinsr_upsample_fn, restore_frames_blur,  # noqa: F401
                       restore_frames_dct, restore_frames_rounds, restore_frames_sinsr,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "elvis_tile_accumulate_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "elvis_tile_normalize_u8": [vp, vp, vp, i32, i32, i32, vp],
     "elvis_sse_u8": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "elvis_block_ssim_u8": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "elvis_u8_to_float": [vp, vp, i32, i32, i32, i32, i32, f32, f32, i32, i32, vp],
     "elvis_float_to_u8": [vp, i32, vp, vp, i32, i32, i32, i32, f32, f32, i32, i32, vp],
     "elvis_conv_packed_weight_bytes": [C.POINTER(ConvDesc)],

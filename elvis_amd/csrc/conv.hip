@@ -20,6 +20,23 @@
 #include <stdlib.h>
 #include <mutex>
 
+// Experiment hooks.  In the product build they are the identity / nothing.  Timing-only variants (no weight or
+// halo staging, no barriers, no stores - all of which produce WRONG results - and the in-kernel phase stamps)
+// are defined in tools/variants/conv_hooks.h and compiled only through tools/variants/conv_variant.hip
+// (tools/build_variant.py), never into libelvis_amd.so.
+#ifndef ELVIS_CONV_HOOKS
+#define ELVIS_STAGE(x) x
+#define ELVIS_STAGE_W(x) x
+#define ELVIS_STAGE_H(x) x
+#define ELVIS_SETPRIO(x)
+#define ELVIS_BARRIER() __syncthreads()
+#define ELVIS_HOOK_SKIP_STORE(tv)
+#define ELVIS_HOOK_STAMP_BEGIN
+#define ELVIS_HOOK_STAMP_LOOP
+#define ELVIS_HOOK_STAMP_EPILOGUE
+#define ELVIS_HOOK_STAMP_END
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -475,14 +492,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         long long xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-#ifdef ELVIS_EXP_COSLOW   /* experiment: co-tile slowest (each XCD streams one co-tile's weights) */
-    const long long ntile_ = (long long)p.tiles_x * p.tiles_y * p.n;
-    const int co_tile = (int)(bid / ntile_);
-    long long t = bid % ntile_;
-#else
     const int co_tile = (int)(bid % p.n_co_tiles);
     long long t = bid / p.n_co_tiles;
-#endif
     // Pixel-tile walk.  Row-major over the full image width puts vertical neighbours tiles_x tiles apart; column
     // strips of `strip` tiles, walked top to bottom, bring the two tiles that share halo rows `strip` tiles apart,
     // inside the set of workgroups resident on the XCD.  (Measured: no change in kernel time on any hot shape -
@@ -508,9 +519,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     const int oy0 = ty * TY, ox0 = tx * TX, co0 = co_tile * TCO;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef ELVIS_EXP_STAMP   /* diagnostic build: per-workgroup phase cycle counts written over the tile's stats slot */
-    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
-#endif
+    ELVIS_HOOK_STAMP_BEGIN
     const int w_co = wave / NW_PX, w_px = wave % NW_PX;
     const int lh = p.upsample ? p.h * 2 : p.h, lw = p.upsample ? p.w_in * 2 : p.w_in;
 
@@ -839,9 +848,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             }
         }
     };
-#ifdef ELVIS_EXP_STAMP
-    unsigned long long stamp1 = 0;
-#endif
     if constexpr (G1) {
         constexpr int STAGE = HALO_BYTES + W_TAP_BYTES;
         constexpr int L = H_PER + W_PER;   // LDS-DMA instructions per thread per stage
@@ -884,9 +890,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 bb[r][e] = pp0 * 64 + ((lq ^ (bit << 1)) << 4);
             }
         const int a_off = HALO_BYTES + w_co * WCO * 1024 + lane_off;
-#ifdef ELVIS_EXP_STAMP
-        stamp1 = __builtin_amdgcn_s_memtime();
-#endif
+        ELVIS_HOOK_STAMP_LOOP
         for (int kc = 0; kc < nkc; ++kc) {
             // this thread's pieces of chunk kc have landed when at most the younger chunks' DMAs remain
             if (kc + G1_NST - 2 < nkc) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G1_NST - 2) * L) : "memory");
@@ -940,9 +944,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     }
     __syncthreads();
 
-#ifdef ELVIS_EXP_STAMP
-    stamp1 = __builtin_amdgcn_s_memtime();
-#endif
+    ELVIS_HOOK_STAMP_LOOP
     // B-fragment addressing with ZERO per-read VALU.  A lane reads halo pixel x + C (x = its pixel at
     // tap (0,0) of the wave's first sub-tile, C a compile-time pixel offset) at byte
     //   (x+C)*64 + ((lq ^ (swz(x+C) << 1)) << 4),   swz(v) = (v >> 2) & 1.
@@ -966,31 +968,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // written to slot (dy+1)%3 and re-armed with the load of row r+2.  One barrier per row step.
     // The next K chunk's halo is staged in two register phases: A loaded at dy=0 / stored after the
     // dy=0 MFMAs, B loaded at dy=1 / stored after the dy=1 MFMAs.
-#ifdef ELVIS_EXP_NOSTAGE   /* timing experiment only: no staging traffic in the loop (wrong results) */
-#define ELVIS_STAGE(x)
-#else
-#define ELVIS_STAGE(x) x
-#endif
-#ifdef ELVIS_EXP_NOW       /* timing experiment only: no weight staging in the loop */
-#define ELVIS_STAGE_W(x)
-#else
-#define ELVIS_STAGE_W(x) ELVIS_STAGE(x)
-#endif
-#ifdef ELVIS_EXP_NOH       /* timing experiment only: no halo staging in the loop */
-#define ELVIS_STAGE_H(x)
-#else
-#define ELVIS_STAGE_H(x) ELVIS_STAGE(x)
-#endif
-#ifdef ELVIS_EXP_SETPRIO
-#define ELVIS_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define ELVIS_SETPRIO(x)
-#endif
-#ifdef ELVIS_EXP_NOBARRIER /* timing experiment only */
-#define ELVIS_BARRIER()
-#else
-#define ELVIS_BARRIER() __syncthreads()
-#endif
 #define ELVIS_ROW_STEP(DY)                                                                             \
     {                                                                                                  \
         const int rslot = TWO ? ((r0 + DY) & 1) : DY;                                                  \
@@ -1103,14 +1080,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         if constexpr (TWO) {
             // every wave is past its last read of this chunk's halo (barrier of the last row step):
             // overwrite the single buffer with the register-staged next chunk
-#ifndef ELVIS_EXP_NOH
-            if (kc + 1 < nkc) {
+            ELVIS_STAGE_H(if (kc + 1 < nkc) {
                 // (with the prologue: GroupNorm-affine + SiLU applied here, in one block between the two
                 // barriers - keeping its LDS table reads out of the row steps leaves their fragment
                 // pipeline intact; the CU's other workgroup runs MFMAs meanwhile)
                 halo_store(kcn, 0, 0, H_PER);
-            }
-#endif
+            })
             __syncthreads();
         } else {
             const int delta = (kc & 1) ? -HALO_BYTES : HALO_BYTES;
@@ -1123,9 +1098,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     }
 #undef ELVIS_ROW_STEP
     }   // !G1
-#ifdef ELVIS_EXP_STAMP
-    const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
-#endif
+    ELVIS_HOOK_STAMP_EPILOGUE
 
     // ---- epilogue
     float st[WCO][4], sq[WCO][4];
@@ -1181,9 +1154,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
                 T* op = (T*)p.out + m * p.cout_pitch + co;
-#ifdef ELVIS_EXP_NOSTORE   /* timing experiment only: stores skipped at run time (never true) */
-                if (p.cout_pitch < 0x7ffffff0) { asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3])); } else
-#endif
+                ELVIS_HOOK_SKIP_STORE(tv)
                 if (ok && !wide16) {
                     if constexpr (sizeof(T) == 2) {
                         half4 hv = {tv[0], tv[1], tv[2], tv[3]};
@@ -1260,9 +1231,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             T tv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
-#ifdef ELVIS_EXP_NOSTORE   /* timing experiment only: stores skipped at run time (never true) */
-            if (p.cout_pitch < 0x7ffffff0) { asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3])); } else
-#endif
+            ELVIS_HOOK_SKIP_STORE(tv)
             if (nv == 4) {
                 if constexpr (sizeof(T) == 2) {
                     half4 hv = {tv[0], tv[1], tv[2], tv[3]};
@@ -1312,21 +1281,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             dst[1] = b;
         }
     }
-#ifdef ELVIS_EXP_STAMP
-    if (p.stats) {
-        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long stamp4 = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        if (tid == 0) {
-            long long tile = ((long long)nimg * p.tiles_y + ty) * p.tiles_x + tx;
-            float* dst = p.stats + (tile * p.cout + co0) * 2;
-            dst[0] = (float)(stamp1 - stamp0); dst[1] = (float)(stamp2 - stamp1);
-            dst[2] = (float)(stamp3 - stamp2); dst[3] = (float)(stamp4 - stamp3);
-            dst[4] = (float)(stamp0 & 0xffffff); dst[5] = (float)__builtin_amdgcn_s_memrealtime();
-        }
-    }
-#endif
+    ELVIS_HOOK_STAMP_END
 }
 
 // tile configuration chosen from cout (shared by pack + launch)

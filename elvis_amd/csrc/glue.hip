@@ -431,3 +431,69 @@ extern "C" int elvis_sse_u8(const uint8_t* a, const uint8_t* b, const uint8_t* m
     ELVIS_CHECK_LAUNCH("elvis_sse_u8");
     return ELVIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// per-block SSIM (utils.py:572-608: pytorch_msssim.ssim on every block_size x block_size patch, data_range 1,
+// 11-tap Gaussian window sigma 1.5, K = (0.01, 0.03), size_average=False).  pytorch_msssim smooths a dimension only
+// when it is at least as long as the window ("valid" convolution) and skips it otherwise, so for blocks smaller than
+// 11 pixels the local means are the pixels themselves and the structure term is identically 1.  One thread per
+// (frame, block): float32 throughout, channels averaged last.  win11: the normalised window (device pointer).
+__global__ __launch_bounds__(64) void block_ssim_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                        float* __restrict__ out, const float* __restrict__ win11, int n,
+                                                        int h, int w, int c, int bs, int by, int bx, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int bxi = (int)(i % bx);
+    const long long t = i / bx;
+    const int byi = (int)(t % by);
+    const int f = (int)(t / by);
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const bool smooth = bs >= 11;
+    const int m = smooth ? bs - 10 : bs;   // side of the SSIM map
+    float wv[11];
+    for (int k = 0; k < 11; ++k) wv[k] = win11[k];
+    float ch_sum = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+        const uint8_t* pa = a + (((long long)f * h + (long long)byi * bs) * w + (long long)bxi * bs) * c + ch;
+        const uint8_t* pb = b + (((long long)f * h + (long long)byi * bs) * w + (long long)bxi * bs) * c + ch;
+        const long long rs = (long long)w * c;
+        float acc = 0.f;
+        for (int y = 0; y < m; ++y)
+            for (int x = 0; x < m; ++x) {
+                float mu1, mu2, xx, yy, xy;
+                if (!smooth) {
+                    const float u = __fdiv_rn((float)pa[y * rs + (long long)x * c], 255.0f), v = __fdiv_rn((float)pb[y * rs + (long long)x * c], 255.0f);
+                    mu1 = u; mu2 = v; xx = u * u; yy = v * v; xy = u * v;
+                } else {
+                    mu1 = mu2 = xx = yy = xy = 0.f;
+                    for (int dy = 0; dy < 11; ++dy) {
+                        float r1 = 0.f, r2 = 0.f, rxx = 0.f, ryy = 0.f, rxy = 0.f;
+                        for (int dx = 0; dx < 11; ++dx) {
+                            const float u = __fdiv_rn((float)pa[(y + dy) * rs + (long long)(x + dx) * c], 255.0f);
+                            const float v = __fdiv_rn((float)pb[(y + dy) * rs + (long long)(x + dx) * c], 255.0f);
+                            r1 += wv[dx] * u; r2 += wv[dx] * v; rxx += wv[dx] * (u * u); ryy += wv[dx] * (v * v); rxy += wv[dx] * (u * v);
+                        }
+                        mu1 += wv[dy] * r1; mu2 += wv[dy] * r2; xx += wv[dy] * rxx; yy += wv[dy] * ryy; xy += wv[dy] * rxy;
+                    }
+                }
+                const float s1 = xx - mu1 * mu1, s2 = yy - mu2 * mu2, s12 = xy - mu1 * mu2;
+                const float cs = (2.f * s12 + C2) / (s1 + s2 + C2);
+                acc += ((2.f * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * cs;
+            }
+        ch_sum += acc / (float)(m * m);
+    }
+    out[i] = ch_sum / (float)c;
+}
+
+extern "C" int elvis_block_ssim_u8(const uint8_t* a, const uint8_t* b, float* ssim_out, const float* win11, int n, int h,
+                                   int w, int c, int block_size, elvis_stream_t stream) {
+    ELVIS_REQUIRE(a && b && ssim_out && win11, "elvis_block_ssim_u8: null pointer");
+    ELVIS_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && block_size > 0 && block_size <= h && block_size <= w,
+                  "elvis_block_ssim_u8: bad shape");
+    const int by = h / block_size, bx = w / block_size;   // floored grid, like utils.py:580-584
+    const long long total = (long long)n * by * bx;
+    hipLaunchKernelGGL(block_ssim_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, b, ssim_out,
+                       win11, n, h, w, c, block_size, by, bx, total);
+    ELVIS_CHECK_LAUNCH("elvis_block_ssim_u8");
+    return ELVIS_OK;
+}

@@ -99,6 +99,13 @@ int elvis_tile_normalize_u8(const float* acc, const float* wsum, uint8_t* out, i
 int elvis_sse_u8(const uint8_t* a, const uint8_t* b, const uint8_t* mask, unsigned long long* sse_out,
                  unsigned long long* cnt_out, int n, int h, int w, int c, elvis_stream_t stream);
 
+/* Per-block SSIM (utils.py:572-608 = pytorch_msssim.ssim per block_size x block_size patch: data_range 1, 11-tap
+ * Gaussian window sigma 1.5 passed in as win11 (device f32[11], normalised), "valid" smoothing that is skipped for
+ * blocks shorter than the window, K = (0.01, 0.03), mean over the map then over channels).  The block grid is
+ * floored (H // block_size, W // block_size); ssim_out: f32 [n, H // b, W // b]. */
+int elvis_block_ssim_u8(const uint8_t* a, const uint8_t* b, float* ssim_out, const float* win11, int n, int h, int w, int c,
+                        int block_size, elvis_stream_t stream);
+
 /* ------------------------------------------------------------------ u8 <-> float */
 
 /* dst[n,h,w,pitch] = (div255 ? src_u8/255 : src_u8) * scale + bias for the first 3 channels

@@ -407,3 +407,41 @@ def psnr_whole(ref, dec, data_range=255.0) -> float:
     """presley.py:235-245 - 10 log10(range^2/mse), inf at 0 (the parity-report PSNR)."""
     mse = np.mean((ref.astype(np.float32) - dec.astype(np.float32)) ** 2)
     return float("inf") if mse == 0 else float(10 * np.log10((data_range ** 2) / mse))
+
+
+def block_ssim(f1: np.ndarray, f2: np.ndarray, block_size: int) -> np.ndarray:
+    """utils.py:572-608 - per-block `pytorch_msssim.ssim(..., data_range=1.0, size_average=False)`.
+
+    PARITY UNPINNED: pytorch_msssim is absent; this restates its published algorithm in float64:
+    11-tap Gaussian window (sigma 1.5, normalised), separable "valid" smoothing that is SKIPPED along a dimension
+    shorter than the window, C1 = 0.01^2, C2 = 0.03^2, ssim_map = luminance * contrast-structure, mean over the
+    map, then over channels."""
+    h, w = f1.shape[:2]
+    by, bx = h // block_size, w // block_size
+    coords = np.arange(11, dtype=np.float32) - 5
+    g = np.exp(-(coords ** 2) / np.float32(2 * 1.5 ** 2)).astype(np.float32)
+    g = (g / g.sum()).astype(np.float64)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+
+    def smooth(x):   # x: (b, b)
+        if x.shape[0] >= 11:
+            x = np.stack([(x[i:i + 11] * g[:, None]).sum(0) for i in range(x.shape[0] - 10)])
+        if x.shape[1] >= 11:
+            x = np.stack([(x[:, j:j + 11] * g[None, :]).sum(1) for j in range(x.shape[1] - 10)], axis=1)
+        return x
+
+    out = np.zeros((by, bx), np.float64)
+    a = f1.astype(np.float32).astype(np.float64) / 255.0
+    b = f2.astype(np.float32).astype(np.float64) / 255.0
+    for iy in range(by):
+        for ix in range(bx):
+            vals = []
+            for c in range(f1.shape[2]):
+                x = a[iy * block_size:(iy + 1) * block_size, ix * block_size:(ix + 1) * block_size, c]
+                y = b[iy * block_size:(iy + 1) * block_size, ix * block_size:(ix + 1) * block_size, c]
+                mu1, mu2 = smooth(x), smooth(y)
+                s1, s2, s12 = smooth(x * x) - mu1 * mu1, smooth(y * y) - mu2 * mu2, smooth(x * y) - mu1 * mu2
+                cs = (2 * s12 + C2) / (s1 + s2 + C2)
+                vals.append((((2 * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * cs).mean())
+            out[iy, ix] = np.mean(vals)
+    return out.astype(np.float32)
