@@ -488,9 +488,9 @@ def dcnv2(x: Act, om: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], g
     [cout, cin, 3, 3] tensor already in the activation dtype on the device."""
     out = new_act(x.n, x.h, x.w, cout, x.t.dtype, x.t.device)
     es = x.t.element_size()
-    # algorithmic bytes per output pixel: the 27*G offset/mask channels, 9 taps x 4 bilinear corners of every
-    # input channel, the output channels (SURVEY.md 8d)
-    px_bytes = (27 * groups + 9 * 4 * x.c + cout) * es
+    # algorithmic HBM bytes per output pixel: the 27*G offset/mask channels, the input channels (each read once:
+    # the 36 bilinear corner reads per channel hit the LDS-resident input window), the output channels
+    px_bytes = (27 * groups + x.c + cout) * es
     with _Timed("dcnv2", "hbm", float(px_bytes) * x.n * x.h * x.w):
         check(lib().elvis_dcnv2(ptr(x.t), ptr(om.t), ptr(weight), ptr(bias), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c,
                                 x.pitch, groups, om.pitch, int(mask_sigmoid), cout, out.pitch, act, _s(x.t)), x.t.device)

@@ -25,15 +25,20 @@ def collect(path, counter):
     return agg
 
 
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 1])[0] + write.get(k, [0, 1])[0])):
-    f, w = fetch.get(k, [0.0, 0]), write.get(k, [0.0, 0])
-    out[k] = {"launches": max(f[1], w[1]),
-              "fetch_bytes_per_launch": 2.0 * 1024.0 * f[0] / max(f[1], 1),   # x2: gfx950 FETCH_SIZE correction
-              "write_bytes_per_launch": 1024.0 * w[0] / max(w[1], 1)}
-    out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled (gfx950)",
-           "kernels": out}, open(sys.argv[3], "w"), indent=1)
-for k in list(out)[:8]:
-    print(k, out[k])
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 1])[0] + write.get(k, [0, 1])[0])):
+        f, w = fetch.get(k, [0.0, 0]), write.get(k, [0.0, 0])
+        out[k] = {"launches": max(f[1], w[1]),
+                  "fetch_bytes_per_launch": 2.0 * 1024.0 * f[0] / max(f[1], 1),   # x2: gfx950 FETCH_SIZE correction
+                  "write_bytes_per_launch": 1024.0 * w[0] / max(w[1], 1)}
+        out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled (gfx950)",
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    for k in list(out)[:8]:
+        print(k, out[k])
+
+
+if __name__ == "__main__":
+    main()
