@@ -121,6 +121,32 @@ template <> __device__ __forceinline__ uint4 prologue_apply<half_t>(uint4 v, con
     return v;
 }
 
+// 256-thread f16 kernels: the same GroupNorm-affine + SiLU on one dword (two halfs) in eleven VALU instructions.
+// The table holds a' = -log2(e) a and b' = -log2(e) b, so u = fma(x, a', b') = -log2(e) t feeds v_exp_f32 directly;
+// d = fma(exp2(u), K, K) = K (1 + e^-t) with K = -log2(e), and u * rcp(d) = t / (1 + e^-t).  hipcc's own code for
+// prologue_apply<half_t> is ~44 issue cycles per element (separate cvt, packed-f32 pairs that need a re-pack, the
+// -log2(e) multiply); this is 32, and the VALU block between the two barriers of a K chunk is what the prologue costs
+// (15-19 % of the kernel: at two waves per SIMD the matrix and vector instructions of the pair do not overlap
+// enough to hide it, tools/experiments/README.md).  (trans -> VALU forwarding: one independent instruction between.)
+__device__ __forceinline__ unsigned prologue_dword_f16(unsigned w, float a0, float a1, float b0, float b1, float K) {
+    float u0, u1, e1;   // (e0 lives in w's register once both halfs have been read)
+    asm volatile(
+        "v_fma_mix_f32 %1, %0, %4, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %0, %5, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_exp_f32 %0, %1\n\t"
+        "v_exp_f32 %3, %2\n\t"
+        "v_fma_f32 %0, %0, %8, %8\n\t"
+        "v_fma_f32 %3, %3, %8, %8\n\t"
+        "v_rcp_f32 %0, %0\n\t"
+        "v_rcp_f32 %3, %3\n\t"
+        "v_mul_f32 %1, %1, %0\n\t"
+        "v_mul_f32 %2, %2, %3\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2"
+        : "+v"(w), "=&v"(u0), "=&v"(u1), "=&v"(e1)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "s"(K));
+    return w;
+}
+
 // Half-vector (8-byte) forms: the halo kernel spreads the prologue over the MFMA taps in pieces.
 __device__ __forceinline__ uint2 prologue_apply_half(uint2 v, const float (&pa)[2], const float (&pb)[2], float) {
     float* f = reinterpret_cast<float*>(&v);
@@ -462,6 +488,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // weights of the 256-thread kernels: LDS-DMA (no staging registers) or register staging
     constexpr bool WDMA = TWO && ELVIS_TWO_WDMA;
     constexpr bool G1 = TWO && KS == 1;
+    // prologue in the hand-written form (prologue_dword_f16): table entries pre-scaled by -log2(e)
+#ifndef ELVIS_ASM_PROLOGUE
+#define ELVIS_ASM_PROLOGUE 1
+#endif
+    constexpr bool PSC = TWO && PRO && sizeof(T) == 2 && ELVIS_ASM_PROLOGUE;
     constexpr int G1_NST = TCO == 64 ? ELVIS_G1_NST64 : ELVIS_G1_NST128;
     constexpr int HCH = HP * 4;
     constexpr int H_PER = (HCH + NT - 1) / NT;
@@ -599,7 +630,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             uint4 v = hreg[i];
-            if (PRO) v = prologue_apply<T>(v, la, lb);
+            if constexpr (PSC) {
+                const float K = -1.4426950408889634f;
+                v.x = prologue_dword_f16(v.x, la[0], la[1], lb[0], lb[1], K);
+                v.y = prologue_dword_f16(v.y, la[2], la[3], lb[2], lb[3], K);
+                v.z = prologue_dword_f16(v.z, la[4], la[5], lb[4], lb[5], K);
+                v.w = prologue_dword_f16(v.w, la[6], la[7], lb[6], lb[7], K);
+            } else if (PRO) {
+                v = prologue_apply<T>(v, la, lb);
+            }
             const bool keep = ch_ok && ((h_ok >> i) & 1u);
             v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
             int chunk = tid + i * NT;
@@ -929,8 +968,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             bool in = cl < (second ? p.cin2 : p.cin);
             long long g = (long long)nimg * ctot + (second ? p.cin : 0) + (in ? cl : 0);
             int q = r / VEC, e = r - q * VEC;
-            ptab[(kc * 4 + q) * 2 * VEC + e] = in ? p.pa[g] : 0.0f;
-            ptab[(kc * 4 + q) * 2 * VEC + VEC + e] = in ? p.pb[g] : 0.0f;
+            const float psc = PSC ? -1.4426950408889634f : 1.0f;
+            ptab[(kc * 4 + q) * 2 * VEC + e] = in ? psc * p.pa[g] : 0.0f;
+            ptab[(kc * 4 + q) * 2 * VEC + VEC + e] = in ? psc * p.pb[g] : 0.0f;
         }
         __syncthreads();
     }
