@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-slots", action="store_true", help="skip the short DCT / Blur slot runs")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of the N > 1 run: nccl (= RCCL over xGMI, the measurement) or gloo (rehearsal of "
+                         "the multi-rank path on a box with fewer GPUs than ranks: ranks then share devices)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU check of the --gpus launcher: gloo ranks, one all-gather of synthetic frames, no kernels")
     return ap.parse_args(argv)
@@ -279,13 +282,20 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the first GPU call
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible")
+    local_dev = local_rank % ndev              # (gloo rehearsal: ranks may share a device)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-        world = dist.get_world_size()          # n_gpus in the line = the ranks RCCL saw
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()          # n_gpus in the line = the ranks the backend saw
 
     from elvis_amd import ops, restore, synth
     from elvis_amd.weights import SinSRConfig
@@ -413,7 +423,9 @@ def main():
                        "timed_region": "host to host: pinned host frames+maps -> H2D, sampler noise (host cores), network, "
                                        "recompose" + (", one RCCL all-gather, rank 0 D2H of the whole sequence" if world > 1 else ", D2H")
                                        + " -> pinned host frames",
-                       "frames_per_gpu": F, "parallelism": f"frame-sharded x{world}, 1 all-gather" if world > 1 else "single GPU",
+                       "frames_per_gpu": F,
+                       "parallelism": (f"frame-sharded x{world}, 1 all-gather ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL on ' + str(ndev) + ' GPU(s) - not a scaling measurement'})"
+                                       if world > 1 else "single GPU"),
                        "gn_fused_into_conv": bool(args.fuse_gn), "frames_per_invocation": args.batch},
             "hbm_resident": {"value": world * F * steps2 / elapsed2, "unit": "frames/s", "steps": steps2,
                              "ms_per_step": elapsed2 / steps2 * 1e3, "same_output_as_host_path": same,
