@@ -25,19 +25,55 @@ def _accum_device(device) -> torch.device:
     return dev
 
 
+def _windows(total: int, size: int, step: int) -> List[Tuple[int, int]]:
+    """[start, end) windows of `size` samples every `step` samples over [0, total), the last ones clipped."""
+    return [(s0, min(s0 + size, total)) for s0 in range(0, total, step)]
+
+
+def _edge_ramp(n: int, width: int, fade_in: bool, fade_out: bool, dtype) -> np.ndarray:
+    """Per-sample weights of a window of n samples: 1 inside, a linear 0->1 ramp over the first `width` samples
+    when the window has a neighbour before it, 1->0 over the last `width` when it has one after it.  Built the
+    way numpy evaluates the reference's in-place products (a `dtype` array of ones multiplied by float64
+    linspace ramps), so the device accumulate can reproduce its rounding; a window thinner than `width` raises
+    the same broadcast ValueError as the reference (utils.py:287-294)."""
+    wgt = np.ones((n,), dtype)
+    if width > 0:
+        if fade_in:
+            wgt[:width] *= np.linspace(0, 1, width)
+        if fade_out:
+            wgt[-width:] *= np.linspace(1, 0, width)
+    return wgt
+
+
+def _temporal_weight(i: int, count: int, overlap: int, has_prev: bool, has_next: bool) -> float:
+    """Weight of frame i of a temporal chunk of `count` frames: (i+1)/(overlap+1) over the first `overlap` frames
+    of a chunk that has a predecessor, mirrored at the end of one that has a successor (utils.py:300-310)."""
+    wgt = 1.0
+    if has_prev and i < overlap:
+        wgt *= (i + 1) / (overlap + 1)
+    if has_next and i >= count - overlap:
+        wgt *= (count - i) / (overlap + 1)
+    return wgt
+
+
 def resource_aware_restore(restore_fn: Callable, frames: List[np.ndarray], tile_size: int = 512, halo: int = 16,
                            chunk_size: int = 8, chunk_overlap: int = 2, max_workers: int = 1, device: str = "cuda",
                            **kwargs) -> List[np.ndarray]:
-    """Spatial tiling (step tile_size-halo) x temporal chunking (step chunk_size-chunk_overlap),
-    linear feather of width halo//2 on interior edges, (i+1)/(overlap+1) temporal ramps,
-    fp32 accumulate / normalise / clip / TRUNCATING uint8 cast (utils.py:176-326)."""
+    """The tiler every `utils.py` restorer goes through (interface and results of utils.py:176-326, pinned by
+    tests/golden/tiler.npz): spatial tiles of `tile_size` every `tile_size - halo` pixels x temporal chunks of
+    `chunk_size` every `chunk_size - chunk_overlap` frames; each task calls
+    `restore_fn(frames=tile_stack, device=, tile_coords=(t0, t1, y0, y1, x0, x1), **kwargs)`; results are blended
+    with linear feathers of width halo // 2 on interior tile edges and temporal ramps, accumulated in fp32,
+    normalised, clipped and TRUNCATED to uint8.  No tiling and no chunking needed -> `restore_fn` is called once,
+    directly.  A task whose `restore_fn` raises is replaced by its input (the reference's behaviour, with a
+    message) - a restorer must not rely on that.  The accumulate / normalise run as HIP kernels."""
     if not frames:
         return []
     h, w = frames[0].shape[:2]
     n_frames = len(frames)
-    do_tiling = tile_size > 0 and (h > tile_size or w > tile_size)
-    do_chunking = chunk_size > 0 and n_frames > chunk_size
-    if not do_tiling and not do_chunking:
+    tiled = tile_size > 0 and (h > tile_size or w > tile_size)
+    chunked = chunk_size > 0 and n_frames > chunk_size
+    if not (tiled or chunked):
         return restore_fn(frames=frames, device=device, **kwargs)
 
     dev = _accum_device(device)
@@ -45,65 +81,40 @@ def resource_aware_restore(restore_fn: Callable, frames: List[np.ndarray], tile_
     acc = torch.zeros((n_frames, h, w, c), dtype=torch.float32, device=dev)
     wsum = torch.zeros((n_frames, h, w), dtype=torch.float32, device=dev)
 
-    if do_tiling:
-        y_steps, x_steps = range(0, h, tile_size - halo), range(0, w, tile_size - halo)
-    else:
-        y_steps, x_steps, tile_size = [0], [0], max(h, w)
-    if do_chunking:
-        t_steps = range(0, n_frames, chunk_size - chunk_overlap)
-    else:
-        t_steps, chunk_size = [0], n_frames
+    side = tile_size if tiled else max(h, w)
+    rows = _windows(h, side, tile_size - halo) if tiled else [(0, h)]
+    cols = _windows(w, side, tile_size - halo) if tiled else [(0, w)]
+    spans = _windows(n_frames, chunk_size, chunk_size - chunk_overlap) if chunked else [(0, n_frames)]
+    tasks = [(t, y, x) for t in spans for y in rows for x in cols]
 
-    def process_task(task):
-        t0, y0, x0 = task
-        t1, y1, x1 = min(t0 + chunk_size, n_frames), min(y0 + tile_size, h), min(x0 + tile_size, w)
-        chunk = [f[y0:y1, x0:x1] for f in frames[t0:t1]]
+    def run(task):
+        (t0, t1), (y0, y1), (x0, x1) = task
+        stack = [f[y0:y1, x0:x1] for f in frames[t0:t1]]
         try:
-            out = restore_fn(frames=chunk, device=device, tile_coords=(t0, t1, y0, y1, x0, x1), **kwargs)
-        except Exception as e:  # same identity fallback as utils.py:251-254
-            print(f"Error processing chunk t={t0}:{t1}, y={y0}:{y1}, x={x0}:{x1}: {e}")
-            out = chunk
-        return (t0, t1, y0, y1, x0, x1, out)
+            return restore_fn(frames=stack, device=device, tile_coords=(t0, t1, y0, y1, x0, x1), **kwargs)
+        except Exception as exc:
+            print(f"restore_fn failed on task t={t0}:{t1}, y={y0}:{y1}, x={x0}:{x1} ({exc}); passing the input through")
+            return stack
 
-    tasks = [(t, y, x) for t in t_steps for y in y_steps for x in x_steps]
     if max_workers > 1:
-        with ThreadPoolExecutor(max_workers=max_workers) as ex:
-            results = list(ex.map(process_task, tasks))
+        with ThreadPoolExecutor(max_workers=max_workers) as pool:
+            outputs = list(pool.map(run, tasks))
     else:
-        results = [process_task(t) for t in tasks]
+        outputs = [run(t) for t in tasks]
 
-    for (t0, t1, y0, y1, x0, x1, out) in results:
-        ch, cw = out[0].shape[:2]
-        # ramps exactly as numpy builds them: a float32 array multiplied in place by float64
-        # linspace ramps (top, bottom, then left, right); a tile thinner than halo//2 raises the
-        # same broadcast ValueError as the reference (utils.py:287-294).
-        wy = np.ones((ch,), np.float32)
-        wx1 = np.ones((cw,), np.float64)
-        wx2 = np.ones((cw,), np.float64)
-        if do_tiling:
-            fe = halo // 2
-            if fe > 0:
-                if y0 > 0:
-                    wy[:fe] *= np.linspace(0, 1, fe)
-                if y1 < h:
-                    wy[-fe:] *= np.linspace(1, 0, fe)
-                if x0 > 0:
-                    wx1[:fe] *= np.linspace(0, 1, fe)
-                if x1 < w:
-                    wx2[-fe:] *= np.linspace(1, 0, fe)
+    feather = halo // 2 if tiled else 0
+    for ((t0, t1), (y0, y1), (x0, x1)), out in zip(tasks, outputs):
+        th, tw = out[0].shape[:2]
+        # the reference multiplies ONE float32 weight image by the y ramps and then by the left and right x ramps;
+        # keeping the two x ramps apart (float64) lets the kernel apply the products in the same order
+        wy = _edge_ramp(th, feather, y0 > 0, y1 < h, np.float32)
+        wx_left = _edge_ramp(tw, feather, x0 > 0, False, np.float64)
+        wx_right = _edge_ramp(tw, feather, False, x1 < w, np.float64)
         tile_d = frames_to_device([np.ascontiguousarray(o) for o in out], dev)
-        wy_d = torch.from_numpy(wy).to(dev)
-        wx1_d = torch.from_numpy(wx1).to(dev)
-        wx2_d = torch.from_numpy(wx2).to(dev)
+        wy_d, wl_d, wr_d = (torch.from_numpy(a).to(dev) for a in (wy, wx_left, wx_right))
         for i in range(len(out)):
-            gt = t0 + i
-            tw = 1.0
-            if do_chunking:
-                if t0 > 0 and i < chunk_overlap:
-                    tw *= (i + 1) / (chunk_overlap + 1)
-                if t1 < n_frames and i >= (len(out) - chunk_overlap):
-                    tw *= (len(out) - i) / (chunk_overlap + 1)
-            ops.tile_accumulate(acc[gt], wsum[gt], tile_d[i], wy_d, wx1_d, wx2_d, y0, x0, float(np.float32(tw)))
+            tw_i = _temporal_weight(i, len(out), chunk_overlap, t0 > 0, t1 < n_frames) if chunked else 1.0
+            ops.tile_accumulate(acc[t0 + i], wsum[t0 + i], tile_d[i], wy_d, wl_d, wr_d, y0, x0, float(np.float32(tw_i)))
 
     final = torch.empty((n_frames, h, w, c), dtype=torch.uint8, device=dev)
     for i in range(n_frames):
