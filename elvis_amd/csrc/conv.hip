@@ -68,6 +68,7 @@ struct ConvArgs {
     int ostr, pad2y, pad2x;  // sub-pixel: ostr 2, pad 1 - par; space-to-depth stride-2 form: ostr 1, pad 0
     int s2d, istr, nkc_c, wfull;   // s2d: K chunk kc = phase (kc / nkc_c) of the full-res input (row stride wfull), istr = 2
     int strip;            // > 0: pixel tiles are walked in column strips of this many tiles (L2 reuse of halo rows)
+    int strip_full;       // tiles_x / strip: whole strips per image row of tiles
 };
 
 template <typename T> struct Frag;
@@ -516,36 +517,45 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     // GroupNorm affine for the slice it stages is two LDS vector reads - no long-lived registers
     float* const ptab = reinterpret_cast<float*>(smem + NHB * HALO_BYTES + NSLOT * W_BYTES);
 
-    long long nblk = (long long)p.n_co_tiles * p.tiles_x * p.tiles_y * p.n;
-    long long bid = blockIdx.x;
+    // tile decode in 32-bit unsigned arithmetic (the host checks the tile count < 2^31): the 64-bit divisions this
+    // replaces were ~700 scalar instructions on every workgroup's critical path, ahead of its first load
+    const unsigned nblk = (unsigned)p.n_co_tiles * (unsigned)p.tiles_x * (unsigned)p.tiles_y * (unsigned)p.n;
+    unsigned bid = blockIdx.x;
     {
-        long long q = nblk / 8, r = nblk % 8;
-        long long xcd = bid % 8, idx = bid / 8;
+        const unsigned q = nblk >> 3, r = nblk & 7u;
+        const unsigned xcd = bid & 7u, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int co_tile = (int)(bid % p.n_co_tiles);
-    long long t = bid / p.n_co_tiles;
+    int co_tile = 0;
+    unsigned t = bid;
+    if (p.n_co_tiles > 1) {
+        t = bid / (unsigned)p.n_co_tiles;
+        co_tile = (int)(bid - t * (unsigned)p.n_co_tiles);
+    }
     // Pixel-tile walk.  Row-major over the full image width puts vertical neighbours tiles_x tiles apart; column
     // strips of `strip` tiles, walked top to bottom, bring the two tiles that share halo rows `strip` tiles apart,
     // inside the set of workgroups resident on the XCD.  (Measured: no change in kernel time on any hot shape -
     // the halo re-reads are served by L2 / the Infinity Cache either way; kept for its lower fabric traffic.)
     int tx, ty, nimg;
     if (p.strip > 0) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        nimg = (int)(t / per_img);
-        int r = (int)(t - (long long)nimg * per_img);
-        const int full = p.tiles_x / p.strip, strip_tiles = p.strip * p.tiles_y;
-        int s = r / strip_tiles;
-        int sw = p.strip;
-        if (s >= full) { s = full; sw = p.tiles_x - full * p.strip; }
+        const unsigned per_img = (unsigned)p.tiles_x * (unsigned)p.tiles_y;
+        const unsigned ni = t / per_img;
+        unsigned r = t - ni * per_img;
+        const unsigned full = (unsigned)p.strip_full, strip_tiles = (unsigned)p.strip * (unsigned)p.tiles_y;
+        unsigned s = r / strip_tiles;
+        unsigned sw = (unsigned)p.strip;
+        if (s >= full) { s = full; sw = (unsigned)p.tiles_x - full * (unsigned)p.strip; }
         r -= s * strip_tiles;
-        ty = r / sw;
-        tx = s * p.strip + (r - ty * sw);
+        const unsigned y = r / sw;
+        nimg = (int)ni;
+        ty = (int)y;
+        tx = (int)(s * (unsigned)p.strip + (r - y * sw));
     } else {
-        tx = (int)(t % p.tiles_x);
-        t /= p.tiles_x;
-        ty = (int)(t % p.tiles_y);
-        nimg = (int)(t / p.tiles_y);
+        const unsigned row = t / (unsigned)p.tiles_x;
+        tx = (int)(t - row * (unsigned)p.tiles_x);
+        const unsigned ni = row / (unsigned)p.tiles_y;
+        ty = (int)(row - ni * (unsigned)p.tiles_y);
+        nimg = (int)ni;
     }
     const int oy0 = ty * TY, ox0 = tx * TX, co0 = co_tile * TCO;
 
@@ -1625,6 +1635,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
         const char* e = getenv("ELVIS_STRIP");   // A/B switch (read per call); 0 = row-major walk
         a.strip = e ? atoi(e) : 8;
         if (a.strip < 0 || a.strip >= a.tiles_x) a.strip = 0;
+        a.strip_full = a.strip > 0 ? a.tiles_x / a.strip : 0;
     }
     const int tyv = halo_ty(d);
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
