@@ -69,6 +69,7 @@ struct ConvArgs {
     int s2d, istr, nkc_c, wfull;   // s2d: K chunk kc = phase (kc / nkc_c) of the full-res input (row stride wfull), istr = 2
     int strip;            // > 0: pixel tiles are walked in column strips of this many tiles (L2 reuse of halo rows)
     int strip_full;       // tiles_x / strip: whole strips per image row of tiles
+    int x3;               // fp32 storage, error-compensated f16 MFMA (ELVIS_F32X3)
 };
 
 template <typename T> struct Frag;
@@ -83,6 +84,38 @@ __device__ __forceinline__ void mma_tile(float4v& acc, const float4v& a, const f
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// X3 (ELVIS_F32X3): fp32 tensors, products on the f16 matrix pipe with the rounding error compensated.  Every operand
+// is split v = hi + lo (hi = f16(v), lo = f16(v - hi): together ~22 significant bits; the MFMA does not flush f16
+// subnormals - tools/probes/mfma_probe.hip) and hi*hi + hi*lo + lo*hi accumulate in fp32: errors ~1e-6 relative
+// instead of f16's 5e-4.  The split happens ONCE per element, outside the MFMA loop: weights are packed and
+// activations staged into LDS as (hi, lo) half pairs in the fp32 slot (x3_pair), so a lane's 16-byte fragment
+// holds 4 channels x (hi, lo) = the eight K slots of one 16x16x32 MFMA.  With the activation fragment B used as
+// it is, A1 = [a_hi, a_hi] x4 gives a_hi*(b_hi + b_lo) and A2 = [a_lo, 0] x4 adds a_lo*b_hi: two 16-cycle MFMAs
+// (2.4x the fp32 MFMA's rate, measured) and 8 VALU per WEIGHT fragment, which 2*WPX MFMAs share.
+__device__ __forceinline__ unsigned x3_pair(float v) {
+    const half_t h = (half_t)v;
+    const half_t l = (half_t)(v - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ uint4 x3_pair4(uint4 v) {
+    return make_uint4(x3_pair(__builtin_bit_cast(float, v.x)), x3_pair(__builtin_bit_cast(float, v.y)),
+                      x3_pair(__builtin_bit_cast(float, v.z)), x3_pair(__builtin_bit_cast(float, v.w)));
+}
+template <bool X3> __device__ __forceinline__ void mma_tile_x(float4v& acc, const half8& a, const half8& b) { mma_tile(acc, a, b); }
+template <bool X3> __device__ __forceinline__ void mma_tile_x(float4v& acc, const float4v& a, const float4v& b) {
+    if constexpr (X3) {
+        const uint4 ap = __builtin_bit_cast(uint4, a);
+        const uint4 a1 = make_uint4(__builtin_amdgcn_perm(ap.x, ap.x, 0x01000100u), __builtin_amdgcn_perm(ap.y, ap.y, 0x01000100u),
+                                    __builtin_amdgcn_perm(ap.z, ap.z, 0x01000100u), __builtin_amdgcn_perm(ap.w, ap.w, 0x01000100u));
+        const uint4 a2 = make_uint4(ap.x >> 16, ap.y >> 16, ap.z >> 16, ap.w >> 16);
+        const half8 B = __builtin_bit_cast(half8, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a1), B, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a2), B, acc, 0, 0, 0);
+    } else {
+        mma_tile(acc, a, b);
+    }
 }
 
 __device__ __forceinline__ int lds_row_off(int row, int q) {
@@ -460,8 +493,8 @@ __global__ __launch_bounds__(64 * NW_CO * NW_PX) void conv_igemm_kernel(ConvArgs
 // ACT = false: no epilogue activation compiled in (act == 0: bias/residual folded into the
 // accumulator start).  The activation code (erf GELU, SiLU with a precise division) is large; keeping
 // it out of the hot instantiations keeps prologue + loop + epilogue inside the instruction cache.
-template <typename T, int TCO, int NT, int TY, bool PRO, int KS = 3, bool ACT = false>
-__global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
+template <typename T, int TCO, int NT, int TY, bool PRO, int KS, bool ACT, bool X3>
+__device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& p) {
     // KS = 3: 3x3 / pad 1 (halo of one pixel).  KS = 1: 1x1 conv / linear layer - the same staging
     // pipeline with no halo and one tap per K chunk (HBM-bound: what matters is bytes in flight).
     // KS = 2: one parity of the sub-pixel decomposition of "nearest-2x upsample + 3x3 conv": the 3x3
@@ -649,6 +682,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             } else if (PRO) {
                 v = prologue_apply<T>(v, la, lb);
             }
+            if constexpr (X3) v = x3_pair4(v);
             const bool keep = ch_ok && ((h_ok >> i) & 1u);
             v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
             int chunk = tid + i * NT;
@@ -679,6 +713,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
         const int c0 = chunk_c0(kc, pixoff_);
         const bool keep = c0 < pitch && ((h_ok >> slot) & 1u);
         uint4 v = hreg[slot];
+        if constexpr (X3) v = x3_pair4(v);
         v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
         int chunk = tid + slot * NT;
         if ((slot + 1) * NT <= HCH || chunk < HCH)
@@ -955,7 +990,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 const int C = (j >> 1) * HX + (j & 1) * 16;
                 frag_t fb = *reinterpret_cast<const frag_t*>(smem + sb + bb[C & 3][(C >> 2) & 1] + C * 64);
 #pragma unroll
-                for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);
+                for (int i = 0; i < WCO; ++i) mma_tile_x<X3>(acc[i][j], fa[i], fb);
             }
         }
         __syncthreads();   // the epilogue reuses LDS for the statistics reduction
@@ -1050,7 +1085,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 }                                                                                      \
                 if (dx + 1 < KS && j < WCO)                                                            \
                     fa[(dx + 1) & 1][j] = *reinterpret_cast<const frag_t*>(wsb + (dx + 1) * W_TAP_BYTES + j * 1024); \
-                _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[dx & 1][i], fb[s & 1]); \
+                _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile_x<X3>(acc[i][j], fa[dx & 1][i], fb[s & 1]); \
             }                                                                                          \
             ELVIS_SETPRIO(0);                                                                          \
             __builtin_amdgcn_sched_group_barrier(0x100, WCO + 1, 0);                                   \
@@ -1068,7 +1103,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
             _Pragma("unroll") for (int j = 0; j < WPX; ++j) {                                          \
                 const int C = ((j >> 1) + DY) * HX + (j & 1) * 16 + dx;                                \
                 frag_t fb = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64); \
-                _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);        \
+                _Pragma("unroll") for (int i = 0; i < WCO; ++i) mma_tile_x<X3>(acc[i][j], fa[i], fb);        \
                 /* PRO: this tap's share of the next chunk's prologue, placed mid-tap */               \
                 if (PRO && DY >= 1 && j == WPX / 2 - 1) {                                              \
                     _Pragma("unroll") for (int pi = 0; pi < 2 * H_PER; ++pi)                           \
@@ -1122,7 +1157,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
                 const int C = (j >> 1) * HX + (j & 1) * 16;
                 frag_t fb = *reinterpret_cast<const frag_t*>(smem + bb[C & 3][(C >> 2) & 1] + C * 64);
 #pragma unroll
-                for (int i = 0; i < WCO; ++i) mma_tile(acc[i][j], fa[i], fb);
+                for (int i = 0; i < WCO; ++i) mma_tile_x<X3>(acc[i][j], fa[i], fb);
             }
             halo_store(kcn, (kc + 1) & 1, 0, H_PER);
             __syncthreads();
@@ -1334,6 +1369,16 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
     ELVIS_HOOK_STAMP_END
 }
 
+template <typename T, int TCO, int NT, int TY, bool PRO, int KS = 3, bool ACT = false>
+__global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(ConvArgs p) {
+    conv3x3_halo_body<T, TCO, NT, TY, PRO, KS, ACT, false>(p);
+}
+// fp32 storage, error-compensated f16 MFMA (ELVIS_F32X3; mma_tile_x): 512-thread kernels only
+template <int TCO, int TY, bool PRO, int KS = 3, bool ACT = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_x3_kernel(ConvArgs p) {
+    conv3x3_halo_body<float, TCO, 512, TY, PRO, KS, ACT, true>(p);
+}
+
 // tile configuration chosen from cout (shared by pack + launch)
 struct TileCfg {
     int tco, tpx, id;
@@ -1400,7 +1445,7 @@ inline int halo_ty(const elvis_conv_desc* d) {
 
 int validate(const elvis_conv_desc* d) {
     ELVIS_REQUIRE(d, "conv: null descriptor");
-    ELVIS_REQUIRE(d->dtype == ELVIS_F32 || d->dtype == ELVIS_F16, "conv: bad dtype %d", d->dtype);
+    ELVIS_REQUIRE(d->dtype == ELVIS_F32 || d->dtype == ELVIS_F16 || d->dtype == ELVIS_F32X3, "conv: bad dtype %d", d->dtype);
     ELVIS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->ho > 0 && d->wo > 0,
                   "conv: bad shape n=%d h=%d w=%d cin=%d cout=%d ho=%d wo=%d", d->n, d->h, d->w, d->cin, d->cout, d->ho, d->wo);
     ELVIS_REQUIRE(d->ksize == 1 || d->ksize == 3 || (d->ksize == 2 && d->subpixel >= 1 && d->subpixel <= 5),
@@ -1441,9 +1486,15 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return ELVIS_OK;
 }
 
-template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false, int TY2 = HALO_TY2> int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false, int TY2 = HALO_TY2, bool X3 = false>
+int launch_halo_p(const ConvArgs& a, hipStream_t stream) {
     if constexpr (!ACT) {
-        if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true, TY2>(a, stream);
+        if (a.act != 0) return launch_halo_p<T, TCO, PRO, KS, NT, true, TY2, X3>(a, stream);
+    }
+    // fp32 storage with the compensated f16 MFMA: the 512-thread kernels with a 64- / 128-channel tile
+    // (narrower layers stay on the exact fp32 MFMA)
+    if constexpr (!X3 && sizeof(T) == 4 && NT == 512 && TCO >= 64) {
+        if (a.x3) return launch_halo_p<T, TCO, PRO, KS, NT, ACT, TY2, true>(a, stream);
     }
     constexpr bool TWO = NT == 256;
     constexpr int TY = (TWO && KS == 1) ? (TCO == 128 ? ELVIS_G1_TY128 : ELVIS_G1_TY64) : TWO ? TY2 : (KS == 3 && PRO && TCO == 128) ? HALO_TY_PRO128 : ((PRO || KS == 1) ? HALO_TY_PRO : HALO_TY);
@@ -1459,8 +1510,10 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false,
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         std::lock_guard<std::mutex> guard(mu);
         if (!attr_set[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const void* fn = nullptr;
+            if constexpr (X3) fn = (const void*)conv3x3_halo_x3_kernel<TCO, TY, PRO, KS, ACT>;
+            else fn = (const void*)conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) {
                 elvis_set_error("conv3x3_halo: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
                 return ELVIS_E_RUNTIME;
@@ -1470,7 +1523,8 @@ template <typename T, int TCO, bool PRO, int KS, int NT = 512, bool ACT = false,
     }
     long long nblk = (long long)a.n_co_tiles * a.tiles_x * a.tiles_y * a.n;
     ELVIS_REQUIRE(nblk < 0x7fffffffLL, "conv: grid too large");
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
+    if constexpr (X3) hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TCO, TY, PRO, KS, ACT>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<T, TCO, NT, TY, PRO, KS, ACT>), dim3((unsigned)nblk), dim3(NT), lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_conv2d(halo)");
     return ELVIS_OK;
 }
@@ -1503,7 +1557,7 @@ template <typename T> int dispatch(const ConvArgs& a, int id, hipStream_t stream
 // ---- weight packing: OIHW f32 -> [tap][kc][co_pad][KC] (T)
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int ctot, int ks,
-                                    int nkc, int co_pad, int KC, long long total, int wco) {
+                                    int nkc, int co_pad, int KC, long long total, int wco, int pairs = 0) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int k = (int)(i % KC);
@@ -1522,6 +1576,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     int ci = kc * KC + k;
     float v = 0.f;
     if (co < cout && ci < ctot) v = w[((long long)co * ctot + ci) * ks * ks + tap];
+    if constexpr (sizeof(T) == 4) {
+        if (pairs) {   // ELVIS_F32X3: (hi, lo) half pair in the fp32 slot
+            reinterpret_cast<unsigned*>(out)[i] = x3_pair(v);
+            return;
+        }
+    }
     out[i] = from_f<T>(v);
 }
 
@@ -1561,7 +1621,7 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
                            (half_t*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total, wco);
     else
         hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           (float*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total, wco);
+                           (float*)packed, d->cout, ctot, d->ksize, nkc, co_pad, KC, total, wco, d->dtype == ELVIS_F32X3 ? 1 : 0);
     ELVIS_CHECK_LAUNCH("elvis_conv_pack_weights");
     return ELVIS_OK;
 }
@@ -1573,6 +1633,16 @@ extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
     return d->n * ((d->ho + ty - 1) / ty) * ((d->wo + HALO_TX - 1) / HALO_TX);
 }
 
+// Does a descriptor with dtype ELVIS_F32X3 run on a compensated-f16 kernel?  (Its weights are packed as (hi, lo)
+// half pairs, which only those kernels read: a host keeps the ELVIS_F32 packing for everything else.)
+static bool x3_eligible(const elvis_conv_desc* d) {
+    return d->dtype == ELVIS_F32X3 && halo_eligible(d) && !getenv("ELVIS_NO_HALO") && choose_tile(d->cout).tco >= 64;
+}
+extern "C" int elvis_conv_x3_eligible(const elvis_conv_desc* d) {
+    if (!d || validate(d)) return 0;
+    return x3_eligible(d) ? 1 : 0;
+}
+
 extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_t n) {
     int rc = validate(d);
     if (rc) return rc;
@@ -1581,6 +1651,10 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
     TileCfg c = choose_tile(d->cout);
     if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
         const bool pro = d->ksize == 3 && d->prologue;
+        if (d->dtype == ELVIS_F32X3 && c.tco >= 64)
+            snprintf(buf, n, "conv3x3_halo_x3_kernel<%d,%d,%s,%d,%s>", c.tco, halo_ty(d), pro ? "true" : "false", d->ksize,
+                     d->act ? "true" : "false");
+        else
         snprintf(buf, n, "conv3x3_halo_kernel<%s,%d,%d,%d,%s,%d,%s>", t, c.tco, (halo_two(d) || halo_g1(d)) ? 256 : 512, halo_ty(d),
                  pro ? "true" : "false", d->ksize, d->act ? "true" : "false");
     } else {
@@ -1598,6 +1672,8 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     ELVIS_REQUIRE(x && w_packed && out, "elvis_conv2d: null pointer");
     ELVIS_REQUIRE(d->cin2 == 0 || x2, "elvis_conv2d: cin2 > 0 but x2 is null");
     ELVIS_REQUIRE(!d->prologue || (pa && pb), "elvis_conv2d: prologue requested without pa/pb");
+    ELVIS_REQUIRE(d->dtype != ELVIS_F32X3 || x3_eligible(d),
+                  "elvis_conv2d: this shape has no compensated-f16 kernel (elvis_conv_x3_eligible): run it as ELVIS_F32");
     ELVIS_REQUIRE(!residual || residual_pitch >= d->cout, "elvis_conv2d: bad residual pitch");
     ELVIS_REQUIRE(((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_packed | (uintptr_t)out) % 16 == 0,
                   "elvis_conv2d: pointers must be 16-byte aligned");
@@ -1638,6 +1714,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
         a.strip_full = a.strip > 0 ? a.tiles_x / a.strip : 0;
     }
     const int tyv = halo_ty(d);
+    a.x3 = d->dtype == ELVIS_F32X3 ? 1 : 0;
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;
     a.tiles_y = ((subpix ? d->h : d->ho) + tyv - 1) / tyv;

@@ -160,15 +160,38 @@ def float_to_u8(x: Act, scale, bias, mode=0, swap_rb=False, want_f32=False):
 
 
 # ----------------------------------------------------------------------------- model kernels
+F32X3_CODE = 2   # include/elvis_amd.h ELVIS_F32X3
+_X3_DEFAULT = False
+
+
+class x3_default:
+    """`with ops.x3_default(True):` - fp32 PackedConv layers built inside run their products on the f16 matrix pipe with
+    the rounding error compensated (ELVIS_F32X3) unless they say otherwise."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _X3_DEFAULT
+        self.prev, _X3_DEFAULT = _X3_DEFAULT, self.on
+
+    def __exit__(self, *exc):
+        global _X3_DEFAULT
+        _X3_DEFAULT = self.prev
+
+
 class PackedConv:
     """A conv/linear layer with weights packed for the implicit-GEMM kernel."""
 
     def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int,
-                 cin2: int = 0):
+                 cin2: int = 0, x3: Optional[bool] = None):
         cout, ctot, kh, kw = weight_oihw.shape
         assert kh == kw and ctot == cin + cin2
         self.cin, self.cin2, self.cout, self.ksize = cin, cin2, cout, kh
         self.dtype, self.device = dtype, device
+        # fp32 tensors, products on the f16 matrix pipe with the rounding error compensated (ELVIS_F32X3, conv.hip
+        # mma_tile_x): ~1e-6 relative instead of f16's 5e-4, at about twice the fp32 MFMA's speed
+        self.x3 = bool(_X3_DEFAULT if x3 is None else x3) and dtype == torch.float32
         d = ConvDesc()
         d.dtype = L.dtype_code(dtype)
         d.n = d.h = d.w = d.ho = d.wo = 1
@@ -181,8 +204,23 @@ class PackedConv:
         w_dev = weight_oihw.to(device=device, dtype=torch.float32).contiguous()
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
         check(lib().elvis_conv_pack_weights(C.byref(d), ptr(w_dev), ptr(self.packed), _s(self.packed)), device)
+        self.packed_x3 = None
+        if self.x3:   # second packing, (hi, lo) half pairs: read by the compensated kernels only (weights_for picks per call)
+            d.dtype = F32X3_CODE
+            self.packed_x3 = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(lib().elvis_conv_pack_weights(C.byref(d), ptr(w_dev), ptr(self.packed_x3), _s(self.packed_x3)), device)
         torch.cuda.current_stream(device).synchronize()  # w_dev may be freed after return
         self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+
+    def weights_for(self, d) -> torch.Tensor:
+        """Packed weights for descriptor `d`; sets d.dtype to ELVIS_F32X3 when this layer is compensated AND the shape
+        has a compensated kernel, otherwise leaves the tensor's dtype code (exact fp32 MFMA / f16)."""
+        if self.packed_x3 is not None:
+            keep, d.dtype = d.dtype, F32X3_CODE
+            if lib().elvis_conv_x3_eligible(C.byref(d)):
+                return self.packed_x3
+            d.dtype = keep
+        return self.packed
 
     def __call__(self, x: Act, x2: Optional[Act] = None, *, stride=1, pad=None, upsample=False, act=0,
                  residual: Optional[Act] = None, prologue=None, out: Optional[Act] = None, ho=None, wo=None,
@@ -212,6 +250,7 @@ class PackedConv:
             pa, pb = prologue
             d.prologue = 1
         stats = None
+        packed = self.weights_for(d)
         tiles = lib().elvis_conv_stats_tiles(C.byref(d))
         if want_stats and tiles > 0:
             stats = torch.empty((tiles, self.cout, 2), dtype=torch.float32, device=x.t.device)
@@ -220,7 +259,7 @@ class PackedConv:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(lib().elvis_conv2d(C.byref(d), ptr(x.t), ptr(x2.t) if x2 is not None else 0, ptr(self.packed),
+        check(lib().elvis_conv2d(C.byref(d), ptr(x.t), ptr(x2.t) if x2 is not None else 0, ptr(packed),
                                  ptr(self.bias), ptr(residual.t) if residual is not None else 0,
                                  residual.pitch if residual is not None else 0, ptr(pa), ptr(pb), ptr(out.t),
                                  ptr(stats), _s(x.t)), x.t.device)
@@ -305,6 +344,7 @@ class PackedUpConv:
             d.ksize, d.stride, d.subpixel, d.act = 2, 1, 1 + k, act
             d.ho, d.wo = 2 * h, 2 * w
             d.cout, d.cout_pitch = self.cout, out.pitch
+            packed = conv.weights_for(d)
             tiles = lib().elvis_conv_stats_tiles(C.byref(d))
             if want_stats and stats is None:
                 stats = torch.empty((4 * tiles, self.cout, 2), dtype=torch.float32, device=x.t.device)
@@ -313,7 +353,7 @@ class PackedUpConv:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            check(lib().elvis_conv2d(C.byref(d), ptr(x.t), 0, ptr(conv.packed), ptr(conv.bias), 0, 0, 0, 0, ptr(out.t),
+            check(lib().elvis_conv2d(C.byref(d), ptr(x.t), 0, ptr(packed), ptr(conv.bias), 0, 0, 0, 0, ptr(out.t),
                                      ptr(sp), _s(x.t)), x.t.device)
             if prof is not None:
                 e1.record()

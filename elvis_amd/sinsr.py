@@ -165,6 +165,13 @@ class SinSRModel:
                  precision: Optional[str] = None):
         self.cfg, self.device, self.dtype, self.fuse_gn = cfg, torch.device(device), dtype, fuse_gn
         self.sec_dtype = {sec: dtype for sec in self.SECTIONS}
+        # "x3" / "mixed..." : fp32 convs run on the f16 matrix pipe with the rounding error compensated (ops.x3_default,
+        # conv.hip mma_tile_x); "f32" / "mixed_exact..." keep the exact fp32 MFMA
+        self.x3 = precision is not None and (precision == "x3" or (precision.startswith("mixed") and not precision.startswith("mixed_exact")))
+        if precision == "x3":
+            self.dtype = dtype = torch.float32
+            self.sec_dtype = {sec: dtype for sec in self.SECTIONS}
+            precision = "f32"
         if precision is not None and precision.startswith("mixed"):
             f16 = tuple(precision.split(":", 1)[1].split("+")) if ":" in precision else self.MIXED_F16_DEFAULT
             unknown = [sec for sec in f16 if sec not in self.SECTIONS]
@@ -178,7 +185,7 @@ class SinSRModel:
         self.subpixel_up = not os.environ.get("ELVIS_NO_SUBPIXEL")
         sd = state_dict if state_dict is not None else make_sinsr_weights(cfg, weight_seed)
         dev = self.device
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), ops.x3_default(self.x3):
             self._build_unet(sd)
             self._build_ae(sd)
         self.codebook = sd["ae.quantize.embedding.weight"].to(device=dev, dtype=torch.float32).contiguous()

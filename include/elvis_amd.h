@@ -40,6 +40,8 @@ extern "C" {
 
 #define ELVIS_F32 0
 #define ELVIS_F16 1
+#define ELVIS_F32X3 2   /* conv only: fp32 tensors; products on the f16 matrix pipe with the rounding error compensated
+                         (operands split hi + lo, ~1e-6 relative), 2-3x the fp32 MFMA's rate.  See elvis_conv_x3_eligible */
 
 #define ELVIS_ROUND_CV2 0      /* 2x2: (s+2)>>2 ; else rint(float(s)*(1.f/area)) half-even */
 #define ELVIS_ROUND_HALF_UP 1  /* (s + area/2) / area */
@@ -174,6 +176,12 @@ int elvis_conv_stats_tiles(const elvis_conv_desc* d);
  * name rocprofv3's kernel trace shows, e.g. "conv3x3_halo_kernel<half,128,256,6,true,3,false>")
  * into buf (NUL-terminated, truncated to n).  For per-kernel profiling (bench.py roofline). */
 int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_t n);
+
+/* 1 when a descriptor with dtype ELVIS_F32X3 has a compensated-f16 kernel (3x3 stride 1 / sub-pixel 2x2 / 1x1 on the
+ * halo-tile kernels with a 64- or 128-channel output tile), else 0.  ELVIS_F32X3 weights are packed by
+ * elvis_conv_pack_weights as (hi, lo) half pairs, which only those kernels read: run every other conv as ELVIS_F32
+ * with weights packed as ELVIS_F32 (elvis_conv2d refuses an ELVIS_F32X3 descriptor that is not eligible). */
+int elvis_conv_x3_eligible(const elvis_conv_desc* d);
 
 /* sums[n, sums_coff + c, 0..1] = sum over the image's tiles of partials[tile][c][0..1] (f64). */
 int elvis_gn_partials_to_sums(const float* partials, int tiles_per_image, int n, int c, double* sums,

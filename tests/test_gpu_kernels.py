@@ -378,3 +378,61 @@ def test_downsample_conv_space_to_depth(gpu_device, cfg):
     direct = ops.PackedConv(wt, b, torch.float16, gpu_device, cin)
     y0 = direct(_act(x, torch.float16, gpu_device), stride=2, pad=0, ho=h // 2, wo=w // 2)
     assert (_nchw(y0) - got).abs().max().item() < TOL[torch.float16]
+
+
+@pytest.mark.parametrize("cfg", [
+    # c1, c2, cout, k, h, w, prologue   (shapes that reach the x3 instantiations: 64- / 128-channel tiles)
+    (128, 0, 128, 3, 40, 70, True),
+    (96, 32, 64, 3, 33, 65, True),       # two inputs, 64-channel tile
+    (64, 0, 256, 3, 24, 40, False),
+    (192, 0, 576, 1, 40, 72, False),     # linear layer
+    (32, 0, 16, 3, 17, 23, True),        # narrow output tile: stays on the exact fp32 MFMA (still must be right)
+])
+def test_conv_compensated_f16_matches_fp32(gpu_device, cfg):
+    """ELVIS_F32X3: fp32 tensors, products on the f16 matrix pipe with the operands split hi + lo.  Bar: the same
+    2e-4 as the exact fp32 kernels against an fp32 CPU conv, and within 2e-4 of the exact fp32 kernel itself
+    (plain f16 operands would be off by ~1e-2 here)."""
+    from elvis_amd import ops
+    c1, c2, cout, k, h, w, pro = cfg
+    g = torch.Generator().manual_seed(21)
+    n = 2
+    x1 = torch.randn(n, c1, h, w, generator=g) * 3.0
+    x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
+    ctot = c1 + c2
+    wt = torch.randn(cout, ctot, k, k, generator=g) / math.sqrt(ctot * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g)
+    pa = torch.rand(n, ctot, generator=g) + 0.5
+    pb = torch.randn(n, ctot, generator=g) * 0.2
+    a1, a2, ar = _act(x1, torch.float32, gpu_device), (_act(x2, torch.float32, gpu_device) if c2 else None), _act(res, torch.float32, gpu_device)
+    kw = dict(residual=ar)
+    if pro:
+        kw["prologue"] = (pa.to(gpu_device), pb.to(gpu_device))
+    x3 = ops.PackedConv(wt, b, torch.float32, gpu_device, c1, c2, x3=True)
+    exact = ops.PackedConv(wt, b, torch.float32, gpu_device, c1, c2, x3=False)
+    assert x3.x3 and not exact.x3
+    y3, ye = _nchw(x3(a1, a2, **kw)), _nchw(exact(a1, a2, **kw))
+    xin = torch.cat([x1, x2], 1) if c2 else x1
+    if pro:
+        xin = F.silu(xin * pa[:, :, None, None] + pb[:, :, None, None])
+    ref = F.conv2d(xin, wt, b, padding=k // 2) + res
+    assert (y3 - ref).abs().max().item() < 2e-4
+    assert (y3 - ye).abs().max().item() < 2e-4
+    f16_err = (F.conv2d(xin.half().float(), wt.half().float(), b, padding=k // 2) + res - ref).abs().max().item()
+    assert f16_err > 10 * (y3 - ref).abs().max().item()      # the compensation is doing something
+
+
+def test_upconv_compensated_f16(gpu_device):
+    """The sub-pixel upsample conv (four 2x2 parity convs) on the compensated path."""
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(22)
+    cin, cout, h, w = 128, 128, 20, 36
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    with ops.x3_default(True):
+        up = ops.PackedUpConv(wt, b, torch.float32, gpu_device, cin)
+    assert all(c.x3 for c in up.par)
+    y = _nchw(up(_act(x, torch.float32, gpu_device)))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    assert (y - ref).abs().max().item() < 2e-4

@@ -219,9 +219,26 @@ def test_full_width_f16_benchmarked_mode_with_vq_lookup(gpu_device):
     assert psnr >= 44.0                       # measured 47.3 dB
 
 
+def test_full_width_compensated_mode_is_fp32_grade(gpu_device):
+    """precision="x3": fp32 tensors everywhere, every conv's products on the f16 matrix pipe with the operands
+    split hi + lo (ELVIS_F32X3).  Same bar as the exact fp32 mode's full-width test."""
+    from elvis_amd.sinsr import SinSRModel
+    from oracle import sinsr_ref as R
+    cfg, sd, lr, noise, ref, _ = _full_width_case(gpu_device, quantize=False)
+    model = SinSRModel(cfg, sd, gpu_device, torch.float16, precision="x3")
+    assert model.dtype == torch.float32 and model.x3
+    u8, f32 = model.forward(lr[None].to(gpu_device), noise.to(gpu_device), want_f32=True)
+    err = (f32[0].cpu() - ref).abs().max().item()
+    print("full-width x3 max-abs", err)
+    assert err <= 1e-4
+    assert np.array_equal(u8[0].cpu().numpy(), R.to_u8(ref).numpy()) or \
+        np.abs(u8[0].cpu().numpy().astype(int) - R.to_u8(ref).numpy().astype(int)).max() <= 1
+
+
 def test_full_width_mixed_mode_meets_the_1e3_bar(gpu_device):
     """The cheapest measured mode inside the north star's tolerance: the 1080p-resolution decoder level in f16,
-    everything else in exact fp32 MFMA (precision="mixed")."""
+    everything else on fp32 tensors with the compensated f16 MFMA (precision="mixed"; "mixed_exact" keeps the fp32
+    MFMA for those sections and lands on the same error)."""
     from elvis_amd.sinsr import SinSRModel
     from oracle import sinsr_ref as R
     cfg, sd, lr, noise, ref, _ = _full_width_case(gpu_device, quantize=False)

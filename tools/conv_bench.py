@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--res", action="store_true", help="add a residual input")
     ap.add_argument("--n", type=int, default=1, help="batch")
+    ap.add_argument("--x3", action="store_true", help="fp32 tensors, error-compensated f16 MFMA (with --dtype f32); also reports the error vs the exact fp32 kernel")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if a.dtype == "f16" else torch.float32
@@ -39,7 +40,8 @@ def main():
         if a.only and a.only not in name:
             continue
         wt = torch.randn(co, c1 + c2, k, k, generator=g) / math.sqrt((c1 + c2) * k * k)
-        conv = ops.PackedConv(wt, torch.randn(co, generator=g), dt, dev, c1, c2)
+        bias_h = torch.randn(co, generator=g)
+        conv = ops.PackedConv(wt, bias_h, dt, dev, c1, c2, x3=a.x3)
         x = ops.Act(torch.randn((a.n, h, w, c1), device=dev, dtype=dt), c1)
         x2 = ops.Act(torch.randn((a.n, h, w, c2), device=dev, dtype=dt), c2) if c2 else None
         pro = None
@@ -49,6 +51,11 @@ def main():
         res = ops.Act(torch.randn((a.n, ho, wo, co), device=dev, dtype=dt), co) if a.res else None
         y = conv(x, x2, upsample=ups, prologue=pro, want_stats=a.stats, residual=res)
         torch.cuda.synchronize()
+        if a.x3:
+            ref = ops.PackedConv(wt, bias_h, dt, dev, c1, c2, x3=False)(x, x2, upsample=ups, prologue=pro, want_stats=a.stats, residual=res)
+            err = (y.t.float() - ref.t.float()).abs().max().item()
+            print(f"  x3 vs exact fp32 kernel: max abs diff {err:.3e} (output rms {ref.t.float().pow(2).mean().sqrt().item():.3f})")
+            del ref
         ts = []
         for _ in range(a.iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

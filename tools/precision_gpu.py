@@ -29,7 +29,7 @@ lr_big = (torch.rand(a.frames, 270, 480, 3, device=dev) * 255).to(torch.uint8)
 print(f"{'mode':32s} max_abs_f32   rms        u8_max  1080p frames/s", flush=True)
 for mode in a.modes:
     dt = torch.float32 if mode == "f32" else torch.float16
-    m = SinSRModel(cfg, sd, dev, dt, precision=mode if mode.startswith("mixed") else None)
+    m = SinSRModel(cfg, sd, dev, dt, precision=mode if (mode.startswith("mixed") or mode == "x3") else None)
     u8, f32 = m.forward(lr[None].to(dev), noise.to(dev), want_f32=True)
     d = (f32[0].cpu() - ref).abs()
     du8 = np.abs(u8[0].cpu().numpy().astype(int) - R.to_u8(ref).numpy().astype(int)).max()
