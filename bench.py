@@ -180,16 +180,17 @@ def cpu_baseline_and_parity(model_mode, dev, fuse_gn):
                "psnr_db_vs_oracle_u8": float("inf") if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse)),
                "max_abs_u8": float(np.abs(got - ref_u8).max()),
                "bit_reproducible": bool(torch.equal(u8, u8b))}
-        if precision is not None:   # 1080p frames/s of this mode (HBM-resident, two frames, one at a time)
-            big = (torch.rand(2, 270, 480, 3, device=dev) * 255).to(torch.uint8)
-            nz = model.make_noise(42, [0, 1], 270, 480)
+        if precision is not None:   # 1080p frames/s of this mode (HBM-resident network, six frames per invocation)
+            nb = 6
+            big = (torch.rand(nb, 270, 480, 3, device=dev) * 255).to(torch.uint8)
+            nz = model.make_noise(42, list(range(nb)), 270, 480)
             model.forward(big[:1], nz[:1])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(2):
-                model.forward(big[i:i + 1], nz[i:i + 1])
+            model.forward(big, nz)
             torch.cuda.synchronize()
-            out["frames_per_s_1080p"] = 2.0 / (time.perf_counter() - t0)
+            out["frames_per_s_1080p"] = nb / (time.perf_counter() - t0)
+            out["frames_per_invocation"] = nb
         del model
         return out
 
