@@ -19,7 +19,9 @@
  *    explicit channel pitch (`*_pitch`, in elements, multiple of 8) so producers can write
  *    straight into channel slices of a wider buffer.
  *  - dtype codes: ELVIS_F32 = 0 (exact-parity mode), ELVIS_F16 = 1 (MFMA fast mode,
- *    fp32 accumulate).
+ *    fp32 accumulate); elvis_conv2d / elvis_conv_pack_weights also take ELVIS_F32X3 = 2
+ *    (fp32 tensors, f16 MFMA with the rounding error compensated: fp32-grade results at
+ *    2-2.5x the fp32 MFMA's rate, for the shapes elvis_conv_x3_eligible accepts).
  */
 #ifndef ELVIS_AMD_H
 #define ELVIS_AMD_H
