@@ -108,13 +108,16 @@ def restore_clip_single4x_device(model: SinSRModel, frames_d: torch.Tensor, leve
         out = torch.empty_like(frames_d)
     if active is None:
         active = (levels_d > 0).flatten(1).any(dim=1).tolist()
+    # frames per network invocation, capped by pixels: 15 frames of 1080p is the largest footprint measured
+    # (~8 GB per 128-channel f16 tensor, a few of them live); results do not depend on it
+    batch = max(1, min(int(batch), (15 * 1080 * 1920 * (2 if model.dtype == torch.float16 else 1)) // (2 * H * W)))
     with torch.cuda.device(model.device):
         todo = [i for i in range(n) if active[i]]
         for i in range(n):
             if not active[i]:
                 out[i:i + 1] = frames_d[i:i + 1]
-        for s0 in range(0, len(todo), max(1, batch)):
-            idx = todo[s0:s0 + max(1, batch)]
+        for s0 in range(0, len(todo), batch):
+            idx = todo[s0:s0 + batch]
             contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
             sel = slice(idx[0], idx[0] + len(idx)) if contiguous else torch.tensor(idx, device=frames_d.device)
             f = frames_d[sel] if contiguous else frames_d[sel].contiguous()
