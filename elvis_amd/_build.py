@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIBPATH = os.path.join(LIBDIR, "libelvis_amd.so")
-SOURCES = ["api.hip", "glue.hip", "misc.hip", "norm.hip", "attn.hip", "dcn.hip", "degrade.hip", "conv.hip"]
+SOURCES = ["conv.hip", "conv_f32.hip", "dcn.hip", "api.hip", "glue.hip", "misc.hip", "norm.hip", "attn.hip", "degrade.hip"]   # slowest first
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
          "-ffp-contract=off"]  # bit-exact glue: no implicit FMA contraction (explicit fmaf where wanted)
@@ -44,7 +44,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "elvis_amd.h"))
     jobs = []
     for src in SOURCES:
