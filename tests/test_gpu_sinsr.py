@@ -236,9 +236,10 @@ def test_full_width_compensated_mode_is_fp32_grade(gpu_device):
 
 
 def test_full_width_mixed_mode_meets_the_1e3_bar(gpu_device):
-    """The cheapest measured mode inside the north star's tolerance: the 1080p-resolution decoder level in f16,
-    everything else on fp32 tensors with the compensated f16 MFMA (precision="mixed"; "mixed_exact" keeps the fp32
-    MFMA for those sections and lands on the same error)."""
+    """precision="mixed": the 1080p-resolution decoder level in f16, everything else on fp32 tensors with the
+    compensated f16 MFMA ("mixed_exact" keeps the fp32 MFMA for those sections and lands on the same error).  On THIS
+    tile it is inside the north star's tolerance; over other tiles it ranges 0.7-1.05e-3 (tools/mixed_margin.py), so
+    the mode that is safely inside the bar is "x3" (test above)."""
     from elvis_amd.sinsr import SinSRModel
     from oracle import sinsr_ref as R
     cfg, sd, lr, noise, ref, _ = _full_width_case(gpu_device, quantize=False)
