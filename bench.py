@@ -207,6 +207,9 @@ def cpu_baseline_and_parity(model_mode, dev, fuse_gn):
                       "decoder level 0 in f16, the rest as x3: inside the bar on this tile, at it on others"}
     if model_mode == "f16":
         parity["cheapest_mode_within_bar"] = dict(mode="x3 (fp32 tensors, compensated f16 MFMA everywhere)", **compare(cfg_c, ref_c, "x3"))
+        vq = compare(cfg, ref_q, "x3")
+        vq.pop("frames_per_s_1080p", None), vq.pop("frames_per_invocation", None)
+        parity["cheapest_mode_within_bar"]["with_vq_lookup"] = vq
         parity["mixed_mode"] = dict(mode="mixed (dec0 in f16, all else as x3)",
                                     note="at the bar, not safely under it: 0.68e-3 .. 1.05e-3 over eight other tiles (tools/mixed_margin.py)",
                                     **compare(cfg_c, ref_c, "mixed"))
