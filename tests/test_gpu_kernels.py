@@ -387,6 +387,8 @@ def test_downsample_conv_space_to_depth(gpu_device, cfg):
     (64, 0, 256, 3, 24, 40, False),
     (192, 0, 576, 1, 40, 72, False),     # linear layer
     (32, 0, 16, 3, 17, 23, True),        # narrow output tile: stays on the exact fp32 MFMA (still must be right)
+    (3, 0, 128, 3, 30, 50, False),       # conv_in: 3 of a K chunk's 16 channels exist
+    (40, 0, 64, 3, 21, 37, True),        # cin not a multiple of 16
 ])
 def test_conv_compensated_f16_matches_fp32(gpu_device, cfg):
     """ELVIS_F32X3: fp32 tensors, products on the f16 matrix pipe with the operands split hi + lo.  Bar: the same
@@ -434,5 +436,19 @@ def test_upconv_compensated_f16(gpu_device):
         up = ops.PackedUpConv(wt, b, torch.float32, gpu_device, cin)
     assert all(c.x3 for c in up.par)
     y = _nchw(up(_act(x, torch.float32, gpu_device)))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    assert (y - ref).abs().max().item() < 2e-4
+
+
+def test_conv_compensated_f16_fused_upsample(gpu_device):
+    """nearest-2x fused into the 3x3 conv (the non-sub-pixel form), compensated path."""
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(23)
+    cin, cout, h, w = 64, 128, 13, 21
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = ops.PackedConv(wt, b, torch.float32, gpu_device, cin, x3=True)
+    y = _nchw(conv(_act(x, torch.float32, gpu_device), upsample=True))
     ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
     assert (y - ref).abs().max().item() < 2e-4
