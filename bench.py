@@ -176,8 +176,12 @@ def cpu_baseline_and_parity(model_mode, dev, fuse_gn):
         ref_u8 = R.to_u8(ref_img).numpy().astype(np.float32)
         got = u8[0].cpu().numpy().astype(np.float32)
         mse = float(np.mean((got - ref_u8) ** 2))
+        # north star: "PSNR within 0.01 dB" - PSNR of either output against one fixed target (the LR tile, nearest x4)
+        target = np.kron(lr.numpy().astype(np.float32), np.ones((4, 4, 1), np.float32))
+        psnr_t = lambda img: float(10 * np.log10(255.0 ** 2 / max(1e-12, float(np.mean((img - target) ** 2)))))
         out = {"max_abs_f32": float((f32[0].cpu() - ref_img).abs().max()),
                "psnr_db_vs_oracle_u8": float("inf") if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse)),
+               "psnr_delta_db_vs_fixed_target": abs(psnr_t(got) - psnr_t(ref_u8)),
                "max_abs_u8": float(np.abs(got - ref_u8).max()),
                "bit_reproducible": bool(torch.equal(u8, u8b))}
         if precision is not None:   # 1080p frames/s of this mode (HBM-resident network, six frames per invocation)
