@@ -9,6 +9,9 @@ import collections, csv, json, re, sys
 def short(name: str) -> str:
     m = re.search(r"(conv3x3_halo_kernel|conv_igemm_kernel)I(DF16_|f)((?:L[ib]\d+E)+)", name)
     if not m:
+        d = re.search(r"((?:conv3x3_halo|conv_igemm|window_attention|layernorm|vq_nearest)\w*)<([^>]*)>", name)   # demangled form
+        if d:
+            return f"{d.group(1)}<{d.group(2).replace(' ', '')}>"
         return name.split("(")[0][:80]
     args = re.findall(r"L([ib])(\d+)E", m.group(3))
     vals = [("true" if v == "1" else "false") if k == "b" else v for k, v in args]
