@@ -278,7 +278,8 @@ extern "C" int elvis_window_attention(const void* qkv, void* out, int dtype, int
     ELVIS_REQUIRE(qkv_pitch >= 3 * heads * head_dim && out_pitch >= heads * head_dim, "elvis_window_attention: bad pitch");
     long long blocks = (long long)n * (h / ws) * (w / ws) * heads;
     ELVIS_REQUIRE(blocks < 0x7fffffffLL, "elvis_window_attention: grid too large");
-    if (dtype == ELVIS_F16 && !getenv("ELVIS_ATTN_VALU")) {
+    static const bool attn_valu = getenv("ELVIS_ATTN_VALU") != nullptr;   // A/B switch, read once
+    if (dtype == ELVIS_F16 && !attn_valu) {
         // MFMA path: one workgroup per window, waves loop over heads
         long long wblocks = (long long)n * (h / ws) * (w / ws);
         hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)wblocks), dim3(64 * ATT_NW), 0, (hipStream_t)stream,

@@ -5,6 +5,16 @@
 // conv_f32.hip: halo != 0 -> launch_halo<float, tco>, else dispatch<float>(id)
 __attribute__((visibility("hidden"))) int elvis_conv_launch_f32_(const void* conv_args, int halo, int tco, int id, hipStream_t stream);
 
+// A/B switches of the experiment tools: read ONCE per process, never on the per-call path
+static bool no_halo() {
+    static const bool v = getenv("ELVIS_NO_HALO") != nullptr;
+    return v;
+}
+static int strip_width() {
+    static const int v = getenv("ELVIS_STRIP") ? atoi(getenv("ELVIS_STRIP")) : 8;   // 0 = row-major tile walk
+    return v;
+}
+
 static void conv_geom(const elvis_conv_desc* d, int* nkc1, int* nkc, int* co_pad) {
     int kc = kc_elems(d->dtype);
     *nkc1 = (d->cin + kc - 1) / kc;
@@ -54,7 +64,7 @@ extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
 // Does a descriptor with dtype ELVIS_F32X3 run on a compensated-f16 kernel?  (Its weights are packed as (hi, lo)
 // half pairs, which only those kernels read: a host keeps the ELVIS_F32 packing for everything else.)
 static bool x3_eligible(const elvis_conv_desc* d) {
-    return d->dtype == ELVIS_F32X3 && halo_eligible(d) && !getenv("ELVIS_NO_HALO") && choose_tile(d->cout).tco >= 64;
+    return d->dtype == ELVIS_F32X3 && halo_eligible(d) && !no_halo() && choose_tile(d->cout).tco >= 64;
 }
 extern "C" int elvis_conv_x3_eligible(const elvis_conv_desc* d) {
     if (!d || validate(d)) return 0;
@@ -67,7 +77,7 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
     ELVIS_REQUIRE(buf && n > 0, "elvis_conv_kernel_name: null buffer");
     const char* t = d->dtype == ELVIS_F16 ? "half" : "float";
     TileCfg c = choose_tile(d->cout);
-    if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
+    if (halo_eligible(d) && !no_halo()) {
         const bool pro = d->ksize == 3 && d->prologue;
         if (d->dtype == ELVIS_F32X3 && c.tco >= 64)
             snprintf(buf, n, "conv3x3_halo_x3_kernel<%d,%d,%s,%d,%s>", c.tco, halo_ty(d), pro ? "true" : "false", d->ksize,
@@ -126,8 +136,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     }
     a.tiles_x = ((subpix ? d->w : d->wo) + HALO_TX - 1) / HALO_TX;
     {
-        const char* e = getenv("ELVIS_STRIP");   // A/B switch (read per call); 0 = row-major walk
-        a.strip = e ? atoi(e) : 8;
+        a.strip = strip_width();
         if (a.strip < 0 || a.strip >= a.tiles_x) a.strip = 0;
         a.strip_full = a.strip > 0 ? a.tiles_x / a.strip : 0;
     }
@@ -136,7 +145,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;
     a.tiles_y = ((subpix ? d->h : d->ho) + tyv - 1) / tyv;
-    if (halo_eligible(d) && !getenv("ELVIS_NO_HALO")) {
+    if (halo_eligible(d) && !no_halo()) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
         hipStream_t st = (hipStream_t)stream;
         if (d->dtype == ELVIS_F16) {

@@ -146,19 +146,21 @@ __global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __rest
     const int gy = tyi * TY_ + ty, gx = txi * TX_ + tx;
     const bool pok = gy < h && gx < w;
     const long long pix = ((long long)ni * h + (pok ? gy : 0)) * w + (pok ? gx : 0);
-    unsigned omw[96];                                                      // the pixel's 189 offset / mask halfs
+    // the pixel's 27*CIN offset / mask halfs (189 for CIN = 7, 216 for CIN = 8), sized by CIN: every offset dword
+    // (index < 9*CIN) and every mask half (index 18*CIN .. 27*CIN-1) below must lie inside the row that was loaded
+    constexpr int n16 = (27 * cin * 2 + 15) / 16;                          // 16-byte pieces that hold them (the host checks
+    unsigned omw[4 * n16];                                                 //  om_pitch >= 8 * n16 halfs)
     {
         const uint4* op = reinterpret_cast<const uint4*>(om + pix * om_pitch);
-        constexpr int n16 = (27 * cin * 2 + 15) / 16;                      // 16-byte pieces that hold them
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i < n16) v = op[i];
+        for (int i = 0; i < n16; ++i) {
+            const uint4 v = op[i];
             omw[4 * i] = v.x; omw[4 * i + 1] = v.y; omw[4 * i + 2] = v.z; omw[4 * i + 3] = v.w;
         }
     }
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     constexpr int mask_h0 = 18 * cin;                                      // first mask half
+    static_assert(((mask_h0 + 9 * cin - 1) >> 1) < 4 * n16 && 9 * cin <= 4 * n16, "offset / mask row does not cover every (group, tap)");
     unsigned pk[4];                                                        // eight packed samples
     const int prow = lane;                                                 // this pixel's row in the wave's images
 #pragma unroll
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __rest
         if (kk < K) {
             const half2v d = __builtin_bit_cast(half2v, omw[kk]);          // (dy, dx) = halfs 2kk, 2kk + 1
             const int mh = mask_h0 + kk;
-            const half2v mm = __builtin_bit_cast(half2v, omw[(mh >> 1) < 96 ? (mh >> 1) : 0]);   // static index
+            const half2v mm = __builtin_bit_cast(half2v, omw[mh >> 1]);    // static index (kk < K: inside the row)
             float m = (float)mm[mh & 1];
             if (mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
             const float sy = (float)(gy + tap / 3 - 1) + (float)d[0], sx = (float)(gx + tap % 3 - 1) + (float)d[1];
@@ -311,7 +313,7 @@ extern "C" int elvis_dcnv2(const void* x, const void* offset_mask, const void* w
     // the tiled gather + MFMA kernel: f16, one channel per deformable group, up to 8 channels, up to 64 outputs
     static const bool no_tile = getenv("ELVIS_DCN_GENERIC") != nullptr;   // A/B switch
     if (dtype == ELVIS_F16 && !no_tile && deformable_groups == cin && (cin == 7 || cin == 8) && x_pitch == 8 && cout <= 64 &&
-        om_pitch % 8 == 0 && (((uintptr_t)x | (uintptr_t)offset_mask | (uintptr_t)out) & 15) == 0) {
+        om_pitch % 8 == 0 && om_pitch >= ((27 * cin * 2 + 15) / 16) * 8 && (((uintptr_t)x | (uintptr_t)offset_mask | (uintptr_t)out) & 15) == 0) {
         const int ksteps = (K + 31) / 32;
         const int tiles_x = (w + TX_ - 1) / TX_, tiles_y = (h + TY_ - 1) / TY_;
         const size_t lds2 = XIN_BYTES + (size_t)ksteps * IMG_BYTES * 5;

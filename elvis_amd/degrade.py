@@ -108,7 +108,13 @@ def filter_frame_downsample(image: np.ndarray, frame_scores: np.ndarray, block_s
 
 def filter_frame_gaussian(image: np.ndarray, frame_scores: np.ndarray, block_size: int, device="cuda:0"):
     """elvis.py:2171-2196 on the device: rounds = round(score * 10) passes of GaussianBlur(5x5, sigma 1) per
-    block (BORDER_REFLECT_101 at the block edges).  Returns (image, int32 rounds map)."""
+    block (BORDER_REFLECT_101 at the block edges).  Returns (image, int32 rounds map).
+
+    PARITY UNPINNED vs cv2: each pass is two float32 separable passes with the `getGaussianKernel(5, 1)` taps and ONE
+    round-half-even uint8 cast (bit-exact with oracle/degrade_ref.py).  cv2.GaussianBlur on CV_8U instead runs 8.8
+    fixed-point coefficients with 16.16 accumulation, so a pixel can differ from OpenCV's by +-1 LSB per pass, and
+    the passes compound (up to 10).  cv2 is absent here and the reference holds no fixture, so the fixed-point form
+    could not be checked and is not restated; same control flow, block grid and border rule as the reference."""
     _check_grid(image, frame_scores, block_size)
     rounds = np.round(frame_scores * 10).astype(np.int32)
     return _one_frame(image, rounds, device, degrade_gaussian_device, block_size), rounds

@@ -68,6 +68,24 @@ def _shard_worker(shard_fn: ShardFn, in_dir: str, out_dir: str, names: Sequence[
         save_frame(restored[i - lo], os.path.join(out_dir, names[i]))
 
 
+def _shard_process(err_path: str, job: tuple) -> None:
+    """Entry point of a spawned per-GPU worker: a failure is written to stderr and to `err_path` as
+    `device / [start, end) / traceback`, so the parent can say WHICH shard failed and why."""
+    import sys
+    import traceback
+    try:
+        _shard_worker(*job)
+    except BaseException:
+        start, end, device_str = job[4], job[5], job[8]
+        msg = f"shard on {device_str}, frames [{start}, {end}):\n{traceback.format_exc()}"
+        sys.stderr.write(msg)
+        try:
+            with open(err_path, "w") as f:
+                f.write(msg)
+        finally:
+            raise SystemExit(1)
+
+
 def _run_shards(shard_fn: ShardFn, in_dir: str, out_dir: str, names: List[str], chunks: List[ChunkSpec],
                 maps: np.ndarray, block_size: int, halo: int, kw: dict) -> None:
     jobs = [(shard_fn, in_dir, out_dir, names, c.start, c.end, maps, block_size, _device_str(c.device), halo, kw)
@@ -75,17 +93,22 @@ def _run_shards(shard_fn: ShardFn, in_dir: str, out_dir: str, names: List[str], 
     if len(jobs) == 1:
         _shard_worker(*jobs[0])
         return
+    import tempfile
     ctx = multiprocessing.get_context("spawn")   # never fork a process that may hold a GPU context
-    procs = [ctx.Process(target=_shard_worker, args=job) for job in jobs]
-    for p in procs:
-        p.start()
-    failed = []
-    for p in procs:
-        p.join()
-        if p.exitcode not in (0, None):
-            failed.append(p.exitcode)
+    with tempfile.TemporaryDirectory(prefix="elvis_shards_") as errdir:
+        errs = [os.path.join(errdir, f"shard{i}.err") for i in range(len(jobs))]
+        procs = [ctx.Process(target=_shard_process, args=(e, job)) for e, job in zip(errs, jobs)]
+        for p in procs:
+            p.start()
+        failed = []
+        for p, e, job in zip(procs, errs, jobs):
+            p.join()
+            if p.exitcode not in (0, None):
+                detail = open(e).read() if os.path.exists(e) else \
+                    f"shard on {job[8]}, frames [{job[4]}, {job[5]}): exit code {p.exitcode} (no traceback: killed?)"
+                failed.append(detail)
     if failed:
-        raise RuntimeError(f"restoration worker(s) exited with non-zero code(s): {failed}")
+        raise RuntimeError("restoration worker(s) failed:\n" + "\n".join(failed))
 
 
 def _frames_and_maps(frames_dir: str, maps, what: str):

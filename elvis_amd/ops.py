@@ -161,6 +161,7 @@ def float_to_u8(x: Act, scale, bias, mode=0, swap_rb=False, want_f32=False):
 
 # ----------------------------------------------------------------------------- model kernels
 F32X3_CODE = 2   # include/elvis_amd.h ELVIS_F32X3
+X3_MFMA_FACTOR = 4   # f16 MFMAs a compensated kernel executes per algorithmic one (conv_kernels.inc mma_tile_x)
 _X3_DEFAULT = False
 
 
@@ -473,8 +474,9 @@ def layernorm(x: Act, gamma, beta, eps=1e-5, out: Optional[Act] = None) -> Act:
 
 def window_attention(qkv: Act, heads, head_dim, ws, shift, bias_table, scale) -> Act:
     out = new_act(qkv.n, qkv.h, qkv.w, heads * head_dim, qkv.t.dtype, qkv.t.device, zero=False)
-    t = ws * ws
-    with _Timed("window_attention", "mfma", 4.0 * t * t * head_dim * heads * qkv.n * (qkv.h // ws) * (qkv.w // ws)):
+    # 4*64^2*32 FLOP per window-head over ~16 KB of q, k, v and output = 32 FLOP/B against a machine balance of ~312:
+    # HBM-bound.  Algorithmic bytes = the qkv tensor read once + the output written once.
+    with _Timed("window_attention", "hbm", 4.0 * heads * head_dim * qkv.t.element_size() * qkv.n * qkv.h * qkv.w):
         check(lib().elvis_window_attention(ptr(qkv.t), ptr(out.t), qkv.dtype_code, qkv.n, qkv.h, qkv.w, heads, head_dim,
                                            ws, shift, qkv.pitch, out.pitch, ptr(bias_table), float(scale), _s(qkv.t)),
               qkv.t.device)
@@ -548,10 +550,13 @@ def temporal_stack(frames_u8: torch.Tensor, f0: int, nsel: int, radius: int, dty
     return Act(out, t)
 
 
-def plane_merge(frames_u8: torch.Tensor, residual: Act, f0: int, nsel: int) -> torch.Tensor:
+def plane_merge(frames_u8: torch.Tensor, residual: Act, f0: int, nsel: int, out=None) -> torch.Tensor:
     _chk_u8(frames_u8)
     _, h, w, _ = frames_u8.shape
-    out = torch.empty((nsel, h, w, 3), dtype=torch.uint8, device=frames_u8.device)
+    if out is None:
+        out = torch.empty((nsel, h, w, 3), dtype=torch.uint8, device=frames_u8.device)
+    elif tuple(out.shape) != (nsel, h, w, 3) or not out.is_contiguous() or out.dtype != torch.uint8:
+        raise ValueError("plane_merge: `out` must be a contiguous uint8 [nsel,H,W,3] tensor")
     check(lib().elvis_plane_merge(ptr(frames_u8), ptr(residual.t), ptr(out), residual.dtype_code, f0, nsel, h, w,
                                   residual.pitch, _s(out)), frames_u8.device)
     return out

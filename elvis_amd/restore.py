@@ -148,12 +148,14 @@ class _HostClipPipeline:
         self.out_d = torch.empty_like(self.frames_d)
         self.levels_d = torch.empty((n, by, bx), dtype=torch.int32, device=dev)
         self.noise_d = torch.empty((n, model.cfg.latent_ch, hp, wp), dtype=torch.float32, device=dev)
-        self.noise_h = torch.empty((n, model.cfg.latent_ch, hp, wp), dtype=torch.float32).pin_memory()
+        # two pinned noise buffers, used by alternate calls: a call returns after ENQUEUEING, so its noise uploads may
+        # still be pending when the next call's generator threads start writing - they write the other buffer, and
+        # `noise_up[k]` (recorded after a call's last upload from buffer k) is waited for before buffer k is rewritten
+        self.noise_hs = [torch.empty((n, model.cfg.latent_ch, hp, wp), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.noise_up = [None, None]
+        self.calls = 0
         self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         self.pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="elvis-noise")
-
-
-_PIPELINES: Dict[tuple, _HostClipPipeline] = {}
 
 
 def restore_clip_single4x_host(model: SinSRModel, frames_h: torch.Tensor, levels_h: torch.Tensor, block_size: int,
@@ -177,18 +179,26 @@ def restore_clip_single4x_host(model: SinSRModel, frames_h: torch.Tensor, levels
         raise ValueError("restore_clip_single4x_host takes host uint8 frames and host int32 maps")
     if out_h is None:
         out_h = torch.empty((n, H, W, 3), dtype=torch.uint8).pin_memory()
-    key = (id(model), n, H, W, by, bx)
+    key = (n, H, W, by, bx)
     with _MODEL_LOCK:
-        pl = _PIPELINES.get(key)
+        # the staging buffers live ON the model object (freed with it), keyed by clip shape
+        pipes = model.__dict__.setdefault("_host_pipelines", {})
+        pl = pipes.get(key)
         if pl is None:
             with torch.cuda.device(model.device):
-                pl = _PIPELINES[key] = _HostClipPipeline(model, n, H, W, by, bx)
+                pl = pipes[key] = _HostClipPipeline(model, n, H, W, by, bx)
     active = (levels_h > 0).flatten(1).any(dim=1).tolist()
-    cfg, (hp, wp) = model.cfg, pl.noise_h.shape[2:]
+    with _MODEL_LOCK:
+        slot = pl.calls & 1
+        pl.calls += 1
+    noise_h = pl.noise_hs[slot]
+    if pl.noise_up[slot] is not None:
+        pl.noise_up[slot].synchronize()   # the call before last uploaded from this buffer: done before it is rewritten
+    cfg, (hp, wp) = model.cfg, noise_h.shape[2:]
 
     def gen(i):   # bit-identical to weights.frame_noise(cfg, seed, frame_indices[i], hp, wp)
         g = torch.Generator().manual_seed(int(seed) * 1000003 + int(frame_indices[i]))
-        torch.randn((1, cfg.latent_ch, hp, wp), generator=g, dtype=torch.float32, out=pl.noise_h[i:i + 1])
+        torch.randn((1, cfg.latent_ch, hp, wp), generator=g, dtype=torch.float32, out=noise_h[i:i + 1])
 
     step = max(1, batch)
     futures = {i: pl.pool.submit(gen, i) for i in range(n) if active[i]}
@@ -204,7 +214,10 @@ def restore_clip_single4x_host(model: SinSRModel, frames_h: torch.Tensor, levels
             with torch.cuda.stream(pl.h2d):
                 pl.frames_d[sel].copy_(frames_h[sel], non_blocking=True)
                 pl.levels_d[sel].copy_(levels_h[sel], non_blocking=True)
-                pl.noise_d[sel].copy_(pl.noise_h[sel], non_blocking=True)
+                pl.noise_d[sel].copy_(noise_h[sel], non_blocking=True)
+                if sel.stop >= n:
+                    pl.noise_up[slot] = torch.cuda.Event()
+                    pl.noise_up[slot].record(pl.h2d)
             compute.wait_stream(pl.h2d)
             restore_clip_single4x_device(model, pl.frames_d[sel], pl.levels_d[sel], block_size,
                                          list(frame_indices[sel]), seed, swap_rb, noise=pl.noise_d[sel],
@@ -354,3 +367,96 @@ def restore_frames_dct(frames: List[np.ndarray], strength_maps: np.ndarray, bloc
         maps_d = maps_to_device(strength_maps, frames_d.shape[0], dev)
         restored = model.restore(frames_d)
         return frames_to_host(ops.recompose_u8(frames_d, restored, maps_d, block_size, 0))
+
+
+# ----------------------------------------------------------------------------- Blur / DCT slots, host to host
+class _HostSlotPipeline:
+    """Persistent staging for `restore_clip_slot_host`: the decoded clip, the working / output clip and the maps in
+    HBM, one upload and one download stream."""
+
+    def __init__(self, dev, n: int, H: int, W: int, by: int, bx: int):
+        self.frames_d = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+        self.out_d = torch.empty_like(self.frames_d)
+        self.maps_d = torch.empty((n, by, bx), dtype=torch.int32, device=dev)
+        self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+
+def restore_clip_slot_host(kind: str, model, frames_h: torch.Tensor, maps_h: torch.Tensor, block_size: int,
+                           out_h: Optional[torch.Tensor] = None, *, batch_size: int = 2, upload_chunk: int = 6,
+                           max_rounds: Optional[int] = None, swap_rb: bool = True, want_device: bool = False):
+    """Host-to-host form of the Blur (`kind="blur"`: the round loop of elvis.py:2947-2981 around the Swin deblurrer) and
+    DCT (`kind="dct"`: one pass of the DCN restorer, `level > 0 ? restored : decoded`) client paths - the timed region
+    SURVEY.md 8(d) asks for on BASELINE configs 4 and 3.  `frames_h` [n,H,W,3] uint8 and `maps_h` [n,By,Bx] int32 in
+    (pinned) host memory -> restored frames in `out_h` (host, pinned).  The clip is uploaded `upload_chunk` frames at a
+    time on a copy stream, each chunk is restored as soon as it (and, for the DCT restorer's temporal window, the
+    chunk after it) has arrived, and goes back on a second copy stream while the next chunk computes.
+
+    Same frames as `restore_frames_blur` / `restore_frames_dct` give: the round loop runs chunk by chunk instead of
+    round by round (frames are independent, so the order is free), and "re-paste where the remaining level <= 0 after
+    r decrements" is evaluated as `map <= r` on the original map - no map is rewritten and nothing is read back from
+    the device inside the call.  Returns after everything has been ENQUEUED; synchronise before reading `out_h`."""
+    if kind not in ("blur", "dct"):
+        raise ValueError(f"unknown slot '{kind}'")
+    n, H, W, _ = frames_h.shape
+    by, bx = maps_h.shape[1:]
+    if H % block_size or W % block_size:
+        raise ValueError("Image dimensions must be divisible by block_size.")
+    if frames_h.is_cuda or maps_h.is_cuda or frames_h.dtype != torch.uint8 or maps_h.dtype != torch.int32 or maps_h.shape[0] != n:
+        raise ValueError("restore_clip_slot_host takes host uint8 frames [n,H,W,3] and host int32 maps [n,By,Bx]")
+    if out_h is None:
+        out_h = torch.empty((n, H, W, 3), dtype=torch.uint8).pin_memory()
+    dev = model.device
+    key = (kind, n, H, W, by, bx)
+    with _MODEL_LOCK:
+        pipes = model.__dict__.setdefault("_host_pipelines", {})
+        pl = pipes.get(key)
+        if pl is None:
+            with torch.cuda.device(dev):
+                pl = pipes[key] = _HostSlotPipeline(dev, n, H, W, by, bx)
+    peak = maps_h.flatten(1).max(dim=1).values.tolist() if n else []      # rounds each frame needs (host copy of the map)
+    step = max(1, int(upload_chunk))
+    halo = model.cfg.radius if kind == "dct" else 0
+    bounds = [(s, min(s + step, n)) for s in range(0, n, step)]
+    with torch.cuda.device(dev):
+        compute = torch.cuda.current_stream(dev)
+        pl.h2d.wait_stream(compute)            # the previous call's kernels may still read the staging buffers
+        pl.d2h.wait_stream(compute)
+        arrived = []
+        with torch.cuda.stream(pl.h2d):
+            for s, e in bounds:
+                pl.frames_d[s:e].copy_(frames_h[s:e], non_blocking=True)
+                pl.maps_d[s:e].copy_(maps_h[s:e], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(pl.h2d)
+                arrived.append(ev)
+        for k, (s, e) in enumerate(bounds):
+            need = k
+            while need + 1 < len(bounds) and bounds[need][1] < min(n, e + halo):
+                need += 1                      # the temporal window of this chunk's last frames
+            compute.wait_event(arrived[need])
+            if kind == "dct":
+                restored = model.restore(pl.frames_d, chunk=batch_size, frame_range=(s, e))
+                ops.recompose_u8(pl.frames_d[s:e], restored, pl.maps_d[s:e], block_size, 0, out=pl.out_d[s:e])
+            else:
+                pl.out_d[s:e].copy_(pl.frames_d[s:e])
+                rounds = max([int(v) for v in peak[s:e]] + [0])
+                if max_rounds is not None:
+                    rounds = min(rounds, max_rounds)
+                for r in range(rounds):
+                    act = [i for i in range(s, e) if peak[i] > r]
+                    for off in range(0, len(act), max(1, batch_size)):
+                        idx = act[off:off + max(1, batch_size)]
+                        if idx == list(range(idx[0], idx[0] + len(idx))):
+                            sel = slice(idx[0], idx[0] + len(idx))
+                            restored = model.restore(pl.out_d[sel], swap_rb=swap_rb)
+                            ops.recompose_u8(pl.frames_d[sel], restored, pl.maps_d[sel], block_size, r, out=pl.out_d[sel])
+                        else:
+                            it = torch.tensor(idx, device=dev)
+                            restored = model.restore(pl.out_d[it].contiguous(), swap_rb=swap_rb)
+                            pl.out_d[it] = ops.recompose_u8(pl.frames_d[it].contiguous(), restored, pl.maps_d[it].contiguous(),
+                                                            block_size, r)
+            pl.d2h.wait_stream(compute)
+            with torch.cuda.stream(pl.d2h):
+                out_h[s:e].copy_(pl.out_d[s:e], non_blocking=True)
+        compute.wait_stream(pl.d2h)
+    return (out_h, pl.out_d) if want_device else out_h

@@ -59,19 +59,24 @@ class DCNRestorer:
             feat = q(feat, act=RELU)
         return self.qe_out(feat)
 
-    def restore(self, frames_d: torch.Tensor, chunk: int = 2) -> torch.Tensor:
+    def restore(self, frames_d: torch.Tensor, chunk: int = 2, frame_range=None) -> torch.Tensor:
         """[F,H,W,3] u8 on the device -> restored [F,H,W,3] u8.  Every colour plane is restored from
-        its 2R+1 temporal window (edge-replicated), `chunk` frames (3*chunk planes) per invocation."""
+        its 2R+1 temporal window (edge-replicated), `chunk` frames (3*chunk planes) per invocation.
+        `frame_range=(a, b)` restores frames [a, b) only - their windows still read the whole clip -
+        and returns [b-a,H,W,3] (the host-to-host pipeline restores a clip range by range)."""
         nf, h, w, _ = frames_d.shape
         if h % 2 or w % 2:
             raise ValueError("DCNRestorer needs even H and W")
-        out = torch.empty_like(frames_d)
+        a, b = (0, nf) if frame_range is None else frame_range
+        if not 0 <= a <= b <= nf:
+            raise ValueError(f"frame_range {frame_range} outside the clip's {nf} frames")
+        out = torch.empty((b - a, h, w, 3), dtype=torch.uint8, device=frames_d.device)
         with torch.cuda.device(self.device):
-            for f0 in range(0, nf, chunk):
-                nsel = min(chunk, nf - f0)
+            for f0 in range(a, b, chunk):
+                nsel = min(chunk, b - f0)
                 planes = ops.temporal_stack(frames_d, f0, nsel, self.cfg.radius, self.dtype)
                 res = self.forward_planes(planes)
-                out[f0:f0 + nsel] = ops.plane_merge(frames_d, res, f0, nsel)
+                ops.plane_merge(frames_d, res, f0, nsel, out=out[f0 - a:f0 - a + nsel])
         return out
 
 

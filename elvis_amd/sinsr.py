@@ -159,11 +159,17 @@ class SinSRModel:
     # listed sections in f16 and the rest in fp32; tools/precision_study.py).
     SECTIONS = ("enc0", "enc1", "enc2", "unet", "dec2", "dec1", "dec0")
     MIXED_F16_DEFAULT = ("dec0",)
+    DEC_SECTIONS = ("dec2", "dec1", "dec0")
 
     def __init__(self, cfg: SinSRConfig = SinSRConfig(), state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device="cuda:0", dtype=torch.float16, weight_seed: int = 0, fuse_gn: bool = True,
                  precision: Optional[str] = None):
         self.cfg, self.device, self.dtype, self.fuse_gn = cfg, torch.device(device), dtype, fuse_gn
+        self.precision = precision or ("f16" if dtype == torch.float16 else "f32")
+        if precision == "dec_f16":
+            # encoder + Swin-UNet compensated (fp32-grade latent: no VQ code flips), the whole decoder - everything
+            # behind the nearest-code lookup - in f16: the u8 frame stays within 1 LSB of the CPU path's
+            precision = "mixed:" + "+".join(self.DEC_SECTIONS)
         self.sec_dtype = {sec: dtype for sec in self.SECTIONS}
         # "x3" / "mixed..." : fp32 convs run on the f16 matrix pipe with the rounding error compensated (ops.x3_default,
         # conv.hip mma_tile_x); "f32" / "mixed_exact..." keep the exact fp32 MFMA

@@ -32,3 +32,10 @@ def test_under_torchrun_env_it_does_not_relaunch():
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     assert json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1     # the environment, not --gpus, is the truth
+
+
+def test_force_dist_runs_the_collective_branch_at_world_one():
+    """`--force-dist`: one rank under a child torchrun, process group initialised, the all-gather executed at world 1
+    (what the GPU box runs with RCCL: tests/test_gpu_dist_world1.py)."""
+    one = _run("--gpus", "1", "--force-dist")
+    assert one["n_gpus"] == 1 and one["order_ok"] and one["backend"] == "gloo"

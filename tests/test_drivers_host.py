@@ -100,7 +100,7 @@ def test_downsample_driver_files_and_errors(tmp_path):
 
 def test_drivers_two_worker_processes(tmp_path):
     """Two devices -> two spawned workers (elvis.py:3124-3158); chunks by the chunk_for_devices rule; the frame
-    index each worker sees is global; a failing worker surfaces as RuntimeError with its exit code."""
+    index each worker sees is global; a failing worker surfaces as RuntimeError with its device, range and traceback."""
     src, dst = tmp_path / "in", tmp_path / "out"
     src.mkdir()
     frames = _write_clip(src, 5, seed=1)
@@ -109,8 +109,10 @@ def test_drivers_two_worker_processes(tmp_path):
     drivers.restore_downsampled_with_sinsr(str(src), str(dst), maps, 8, devices=two, _shard_fn=_hooks.plus_device_tag)
     for i, f in enumerate(frames):
         assert np.array_equal(frameio.load_frame(dst / f"{i + 1:05d}.png"), _hooks.plus_device_tag([f], maps[i:i + 1], 8, None, i)[0])
-    with pytest.raises(RuntimeError, match="non-zero"):
+    # a failing worker names its device, its frame range and the exception
+    with pytest.raises(RuntimeError, match=r"(?s)shard on (cpu|meta), frames \[\d, \d\).*RuntimeError: boom") as ei:
         drivers.restore_downsampled_with_sinsr(str(src), str(dst), maps, 8, devices=two, _shard_fn=_hooks.failing)
+    assert "frames [0, 3)" in str(ei.value) and "frames [3, 5)" in str(ei.value)
 
 
 def test_in_place_drivers(tmp_path):

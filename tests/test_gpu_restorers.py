@@ -46,6 +46,28 @@ def test_dcnv2_kernel(gpu_device, dtype, tol):
     assert (y2.t[..., :16].cpu().permute(0, 3, 1, 2) - ref2).abs().max().item() < 1e-4
 
 
+def test_dcnv2_tile_kernel_eight_groups(gpu_device):
+    """cin = 8, deformable_groups = 8, f16: the tiled kernel's other instantiation.  Its offset / mask row is 216 halfs
+    (27 x 16-byte pieces), with the masks of groups 5-7 in the last three pieces (a fixed 24-piece load
+    read an offset dword in their place)."""
+    from elvis_amd import ops
+    from oracle import restorers_ref as R
+    g = torch.Generator().manual_seed(22)
+    n, c, h, w, G, co = 1, 8, 21, 37, 8, 48
+    x = torch.rand(n, c, h, w, generator=g)
+    off = torch.randn(n, 18 * G, h, w, generator=g) * 2.0
+    mlog = torch.randn(n, 9 * G, h, w, generator=g) * 2.0           # spread masks: a wrong mask moves the output by O(0.1)
+    wt = torch.randn(co, c, 3, 3, generator=g) / 8
+    b = torch.randn(co, generator=g) * 0.1
+    dt = torch.float16
+    xa, oma = _act(x, dt, gpu_device), _act(torch.cat([off, mlog], 1), dt, gpu_device)
+    y = ops.dcnv2(xa, oma, wt.to(gpu_device, dt).contiguous(), b.to(gpu_device), G, co, mask_sigmoid=True, act=0)
+    q = lambda t: t.to(dt).float()
+    ref = R.dcnv2(q(x), q(off), torch.sigmoid(q(mlog)), q(wt), b, G)
+    got = y.t[..., :co].float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("dtype,lsb", [(torch.float32, 1), (torch.float16, 3)])
 def test_dcn_restorer_vs_oracle(gpu_device, dtype, lsb):
     from elvis_amd.restorers import DCNRestorer

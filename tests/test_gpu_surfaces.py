@@ -206,3 +206,43 @@ def test_host_to_host_pipeline_equals_device_path(gpu_device):
     assert torch.equal(out[3], fh[3])
     with pytest.raises(ValueError):
         restore.restore_clip_single4x_host(model, fh.to(gpu_device), lh, 8, gidx)
+    # consecutive clips with DIFFERENT frame indices and no device sync in between (the pinned noise
+    # buffer of call k must not be rewritten by call k+1's generator before call k's uploads have run)
+    clips = [[100 * c + i for i in range(5)] for c in range(4)]
+    wants = [restore.restore_clip_single4x_device(model, fh.to(gpu_device), lh.to(gpu_device), 8, g, batch=2).cpu() for g in clips]
+    assert not torch.equal(wants[0], wants[1])                  # the sampler noise does depend on the frame index
+    outs = [torch.empty_like(fh).pin_memory() for _ in clips]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(200_000_000)                              # keep the device busy so the calls below run ahead of it
+    for g, o in zip(clips, outs):
+        restore.restore_clip_single4x_host(model, fh, lh, 8, g, o, batch=2)
+    torch.cuda.synchronize()
+    for o, w_ in zip(outs, wants):
+        assert torch.equal(o, w_)
+
+
+def test_slot_host_pipelines_equal_the_frames_level_drivers(gpu_device):
+    """restore_clip_slot_host (pinned host in/out, chunked uploads, chunk-outer round loop, `map <= r` on the original
+    map) restores exactly what restore_frames_blur / restore_frames_dct restore - also for a ragged last chunk, rounds
+    that differ per frame, an untouched frame, and when called twice in a row."""
+    import elvis_amd as E
+    from elvis_amd import restore
+    frames = _frames(7, 64, 96, 31)
+    rng = np.random.default_rng(32)
+    bm = rng.integers(0, 4, size=(7, 8, 12)).astype(np.int32)
+    bm[2] = 0
+    bm[5] = np.minimum(bm[5], 1)
+    fh = torch.from_numpy(np.stack(frames)).pin_memory()
+    for kind, fn, kw in (("blur", E.restore_frames_blur, dict(batch_size=2)), ("dct", E.restore_frames_dct, {})):
+        want = np.stack(fn(frames, bm, 8, gpu_device, **kw))
+        model = restore._get_restorer(kind, gpu_device, False)
+        mh = torch.from_numpy(bm).pin_memory()
+        out = torch.empty_like(fh).pin_memory()
+        for _ in range(2):
+            out.zero_()
+            restore.restore_clip_slot_host(kind, model, fh, mh, 8, out, batch_size=2, upload_chunk=3)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.numpy(), want), kind
+        assert np.array_equal(out[2].numpy(), frames[2])
+    with pytest.raises(ValueError):
+        restore.restore_clip_slot_host("blur", model, fh.to(gpu_device), mh, 8)
