@@ -243,10 +243,11 @@ def _kernel_table(conv_prof, other_prof, el, mode, conv_mfma_factor=None):
         rec = {"kernel": name, "bound": "mfma", "achieved": work / sec / 1e12, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
                "frac": work / sec / 1e12 / PEAK_TFLOPS[mode], "launches": cnt, "avg_launch_ms": sec / cnt * 1e3,
                "time_share": sec / el}
-        if conv_mfma_factor and "_x3_" in name:
-            # the compensated kernels run `factor` f16 MFMAs per algorithmic one (hi*hi + hi*lo + lo*hi)
-            rec["executed_mfma_tflops"] = rec["achieved"] * conv_mfma_factor
-            rec["executed_mfma_frac"] = rec["frac"] * conv_mfma_factor
+        if conv_mfma_factor and conv_mfma_factor(name) > 1:
+            # the compensated kernels run 3 (planar) or 4 (interleaved) f16 MFMAs per algorithmic one
+            rec["mfma_per_algorithmic"] = conv_mfma_factor(name)
+            rec["executed_mfma_tflops"] = rec["achieved"] * conv_mfma_factor(name)
+            rec["executed_mfma_frac"] = rec["frac"] * conv_mfma_factor(name)
         cands.append((sec, rec))
     for (name, bound), (work, sec, cnt) in _aggregate([((n, b), w, e0, e1) for n, b, w, e0, e1 in other_prof]).items():
         peak, unit, scale = (PEAK_TFLOPS[mode], "TFLOP/s", 1e12) if bound == "mfma" else (HBM_PEAK_GBS, "GB/s", 1e9)
@@ -351,12 +352,12 @@ def mode_run(precision, dev, cfg, frames_h, levels_h, B, gidx, mode_parity):
     ops.CONV_PROFILER = prof
     el = _timed_steps(step, 0, 1)
     ops.CONV_PROFILER = None
-    table = _kernel_table(prof, [], el, "f16", conv_mfma_factor=ops.X3_MFMA_FACTOR)
+    table = _kernel_table(prof, [], el, "f16", conv_mfma_factor=ops.x3_mfma_factor)
     tot_fl = sum(w for _, w, _, _ in prof)
     tot_s = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
     res = {"mode": precision, "value": F / sec, "unit": "frames/s", "steps": 3, "warmup": 1, "ms_per_step": sec * 1e3,
            "frames_per_invocation": batch, "timed_region": "host to host, as `value`",
-           "roofline": dict(table[0], note=f"peak = dense f16 MFMA; a compensated (x3) kernel executes {ops.X3_MFMA_FACTOR} f16 MFMAs per "
+           "roofline": dict(table[0], note="peak = dense f16 MFMA; a compensated kernel executes `mfma_per_algorithmic` f16 MFMAs per "
                                            "algorithmic one: `achieved` / `frac` count algorithmic FLOPs, `executed_mfma_*` the matrix work") if table else None,
            "second_kernel": table[1] if len(table) > 1 else None,
            "all_conv_kernels": {"achieved": tot_fl / tot_s / 1e12, "time_share_of_step": tot_s / el},
@@ -391,7 +392,7 @@ def staged_run(dev, cfg, frames_h, levels_h, B, first, nframes=6):
 
 
 def staged_parity(dev):
-    """Staged schedule vs glue_ref.upscale_adaptive driven by the ORACLE network (full-width config) on a 64x64 frame,
+    """Staged schedule vs glue_ref.upscale_adaptive driven by the ORACLE network (full-width config) on a 320x320 frame,
     block 8, levels 0-3: u8 LSB of the f16 default and of the in-tolerance modes."""
     import numpy as np
     import torch
@@ -401,9 +402,10 @@ def staged_parity(dev):
     cfg = SinSRConfig()
     sd = make_sinsr_weights(cfg, 0)
     rng = np.random.default_rng(7)
-    base = rng.random((18, 18, 3))
-    frame = np.clip(np.kron(base, np.ones((4, 4, 1)))[:64, :64] * 255 + rng.normal(0, 4, (64, 64, 3)), 0, 255).astype(np.uint8)
-    levels = rng.integers(0, 4, size=(1, 8, 8)).astype(np.int32)
+    S = 320   # /8 -> 40x40 (reflect-padded to 64 inside the UNet: the pad must stay below the size), x4 -> 160, x4 -> 640, /2 -> 320
+    base = rng.random((S // 4 + 2, S // 4 + 2, 3))
+    frame = np.clip(np.kron(base, np.ones((4, 4, 1)))[:S, :S] * 255 + rng.normal(0, 4, (S, S, 3)), 0, 255).astype(np.uint8)
+    levels = rng.integers(0, 4, size=(1, S // 8, S // 8)).astype(np.int32)
     levels[0, 0, 0] = 3
 
     def up(img_bgr):
@@ -413,7 +415,7 @@ def staged_parity(dev):
         return np.ascontiguousarray(R.to_u8(o).numpy()[:, :, ::-1])
 
     ref = glue_ref.upscale_adaptive(frame, levels[0], 8, up, step=4).astype(int)
-    out = {"tile": "64x64 frame, block 8, levels 0-3, full-width config; oracle = glue_ref.upscale_adaptive + the CPU network"}
+    out = {"tile": f"{S}x{S} frame, block 8, levels 0-3, full-width config; oracle = glue_ref.upscale_adaptive + the CPU network"}
     for prec in (None, "dec_f16", "x3"):
         got = restore.restore_frames_sinsr([frame], levels, 8, dev, cfg=cfg, schedule="staged", precision=prec)[0].astype(int)
         d = np.abs(got - ref)

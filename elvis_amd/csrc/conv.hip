@@ -4,6 +4,9 @@
 
 // conv_f32.hip: halo != 0 -> launch_halo<float, tco>, else dispatch<float>(id)
 __attribute__((visibility("hidden"))) int elvis_conv_launch_f32_(const void* conv_args, int halo, int tco, int id, hipStream_t stream);
+// conv_f32.hip: the planar compensated form's weight packing (conv_x3p.inc)
+__attribute__((visibility("hidden"))) int elvis_conv_pack_x3p_(const float* w_oihw, void* packed, int cout, int ctot, int nkc, int n_co_tiles,
+                                                              int tco, hipStream_t stream);
 
 // A/B switches of the experiment tools: read ONCE per process, never on the per-call path
 static bool no_halo() {
@@ -16,7 +19,7 @@ static int strip_width() {
 }
 
 static void conv_geom(const elvis_conv_desc* d, int* nkc1, int* nkc, int* co_pad) {
-    int kc = kc_elems(d->dtype);
+    int kc = kc_of(d);
     *nkc1 = (d->cin + kc - 1) / kc;
     *nkc = *nkc1 + (d->cin2 > 0 ? (d->cin2 + kc - 1) / kc : 0);
     TileCfg t = choose_tile(d->cout);
@@ -27,7 +30,7 @@ extern "C" size_t elvis_conv_packed_weight_bytes(const elvis_conv_desc* d) {
     if (!d || d->cin <= 0 || d->cout <= 0) return 0;
     int nkc1, nkc, co_pad;
     conv_geom(d, &nkc1, &nkc, &co_pad);
-    return (size_t)d->ksize * d->ksize * nkc * co_pad * 64;
+    return (size_t)d->ksize * d->ksize * nkc * co_pad * (x3_planar_fmt(d) ? 128 : 64);   // planar: a hi and a lo row per 32 channels
 }
 
 extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_oihw, void* packed,
@@ -37,6 +40,10 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
     ELVIS_REQUIRE(w_oihw && packed, "elvis_conv_pack_weights: null pointer");
     int nkc1, nkc, co_pad;
     conv_geom(d, &nkc1, &nkc, &co_pad);
+    if (x3_planar_fmt(d)) {
+        const int tco = choose_tile(d->cout).tco;
+        return elvis_conv_pack_x3p_(w_oihw, packed, d->cout, d->cin + d->cin2, nkc, co_pad / tco, tco, (hipStream_t)stream);
+    }
     int KC = kc_elems(d->dtype);
     // with two inputs the packed K axis is [cin padded to nkc1*KC | cin2]; cin % KC == 0 is
     // enforced in that case so the source channel index is simply ci.
@@ -64,7 +71,9 @@ extern "C" int elvis_conv_stats_tiles(const elvis_conv_desc* d) {
 // Does a descriptor with dtype ELVIS_F32X3 run on a compensated-f16 kernel?  (Its weights are packed as (hi, lo)
 // half pairs, which only those kernels read: a host keeps the ELVIS_F32 packing for everything else.)
 static bool x3_eligible(const elvis_conv_desc* d) {
-    return d->dtype == ELVIS_F32X3 && halo_eligible(d) && !no_halo() && choose_tile(d->cout).tco >= 64;
+    if (!(d->dtype == ELVIS_F32X3 && halo_eligible(d) && !no_halo() && choose_tile(d->cout).tco >= 64)) return false;
+    // a layer packed in the planar format runs on the planar kernel only (plain 3x3 / stride 1 / pad 1 geometry)
+    return !x3_planar_fmt(d) || x3_planar_run(d);
 }
 extern "C" int elvis_conv_x3_eligible(const elvis_conv_desc* d) {
     if (!d || validate(d)) return 0;
@@ -79,7 +88,9 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
     TileCfg c = choose_tile(d->cout);
     if (halo_eligible(d) && !no_halo()) {
         const bool pro = d->ksize == 3 && d->prologue;
-        if (d->dtype == ELVIS_F32X3 && c.tco >= 64)
+        if (x3_planar_run(d))
+            snprintf(buf, n, "conv3x3_x3p_kernel<%d,%d,%s,%s>", c.tco, halo_ty(d), pro ? "true" : "false", d->act ? "true" : "false");
+        else if (d->dtype == ELVIS_F32X3 && c.tco >= 64)
             snprintf(buf, n, "conv3x3_halo_x3_kernel<%d,%d,%s,%d,%s>", c.tco, halo_ty(d), pro ? "true" : "false", d->ksize,
                      d->act ? "true" : "false");
         else
@@ -141,7 +152,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
         a.strip_full = a.strip > 0 ? a.tiles_x / a.strip : 0;
     }
     const int tyv = halo_ty(d);
-    a.x3 = d->dtype == ELVIS_F32X3 ? 1 : 0;
+    a.x3 = d->dtype == ELVIS_F32X3 ? (x3_planar_run(d) ? 2 : 1) : 0;
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;
     a.tiles_y = ((subpix ? d->h : d->ho) + tyv - 1) / tyv;

@@ -161,7 +161,12 @@ def float_to_u8(x: Act, scale, bias, mode=0, swap_rb=False, want_f32=False):
 
 # ----------------------------------------------------------------------------- model kernels
 F32X3_CODE = 2   # include/elvis_amd.h ELVIS_F32X3
-X3_MFMA_FACTOR = 4   # f16 MFMAs a compensated kernel executes per algorithmic one (conv_kernels.inc mma_tile_x)
+
+
+def x3_mfma_factor(kernel_name: str) -> int:
+    """f16 MFMAs a kernel executes per algorithmic one: 3 for the planar compensated form (conv_x3p.inc: hi*hi + hi*lo +
+    lo*hi on full-K fragments), 4 for the interleaved form (conv_kernels.inc mma_tile_x), 1 otherwise."""
+    return 3 if "_x3p_" in kernel_name else 4 if "_x3_" in kernel_name else 1
 _X3_DEFAULT = False
 
 
@@ -208,6 +213,7 @@ class PackedConv:
         self.packed_x3 = None
         if self.x3:   # second packing, (hi, lo) half pairs: read by the compensated kernels only (weights_for picks per call)
             d.dtype = F32X3_CODE
+            nbytes = lib().elvis_conv_packed_weight_bytes(C.byref(d))   # its own size: the planar 3x3 format pads K to 32
             self.packed_x3 = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(lib().elvis_conv_pack_weights(C.byref(d), ptr(w_dev), ptr(self.packed_x3), _s(self.packed_x3)), device)
         torch.cuda.current_stream(device).synchronize()  # w_dev may be freed after return

@@ -43,7 +43,10 @@ extern "C" {
 #define ELVIS_F32 0
 #define ELVIS_F16 1
 #define ELVIS_F32X3 2   /* conv only: fp32 tensors; products on the f16 matrix pipe with the rounding error compensated
-                         (operands split hi + lo, ~1e-6 relative), 2-3x the fp32 MFMA's rate.  See elvis_conv_x3_eligible */
+                         (operands split hi + lo, ~1e-6 relative), 2-4x the fp32 MFMA's rate.  See elvis_conv_x3_eligible.
+                         OPERAND RANGE: hi = f16(v), so every activation (after the fused prologue) and weight must
+                         satisfy |v| < 65504; beyond that the result is non-finite (inf / NaN), never silently wrong.
+                         Run a layer whose operands can exceed the f16 range as ELVIS_F32. */
 
 #define ELVIS_ROUND_CV2 0      /* 2x2: (s+2)>>2 ; else rint(float(s)*(1.f/area)) half-even */
 #define ELVIS_ROUND_HALF_UP 1  /* (s + area/2) / area */
@@ -181,8 +184,9 @@ int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_t n);
 
 /* 1 when a descriptor with dtype ELVIS_F32X3 has a compensated-f16 kernel (3x3 stride 1 / sub-pixel 2x2 / 1x1 on the
  * halo-tile kernels with a 64- or 128-channel output tile), else 0.  ELVIS_F32X3 weights are packed by
- * elvis_conv_pack_weights as (hi, lo) half pairs, which only those kernels read: run every other conv as ELVIS_F32
- * with weights packed as ELVIS_F32 (elvis_conv2d refuses an ELVIS_F32X3 descriptor that is not eligible). */
+ * elvis_conv_pack_weights as f16 (hi, lo) parts - planes of 32 channels for 3x3 layers (three MFMAs per 32 channels),
+ * interleaved pairs otherwise (four) - which only those kernels read: run every other conv as ELVIS_F32 with weights
+ * packed as ELVIS_F32 (elvis_conv2d refuses an ELVIS_F32X3 descriptor that is not eligible). */
 int elvis_conv_x3_eligible(const elvis_conv_desc* d);
 
 /* sums[n, sums_coff + c, 0..1] = sum over the image's tiles of partials[tile][c][0..1] (f64). */

@@ -389,6 +389,8 @@ def test_downsample_conv_space_to_depth(gpu_device, cfg):
     (32, 0, 16, 3, 17, 23, True),        # narrow output tile: stays on the exact fp32 MFMA (still must be right)
     (3, 0, 128, 3, 30, 50, False),       # conv_in: 3 of a K chunk's 16 channels exist
     (40, 0, 64, 3, 21, 37, True),        # cin not a multiple of 16
+    (160, 160, 160, 3, 26, 34, True),    # planar form: two 5-chunk inputs, cout padded 160 -> 192 (three 64-channel tiles)
+    (256, 0, 128, 3, 25, 64, False),     # planar form: 8 K chunks, ragged last tile row
 ])
 def test_conv_compensated_f16_matches_fp32(gpu_device, cfg):
     """ELVIS_F32X3: fp32 tensors, products on the f16 matrix pipe with the operands split hi + lo.  Bar: the same
@@ -422,6 +424,57 @@ def test_conv_compensated_f16_matches_fp32(gpu_device, cfg):
     assert (y3 - ye).abs().max().item() < 2e-4
     f16_err = (F.conv2d(xin.half().float(), wt.half().float(), b, padding=k // 2) + res - ref).abs().max().item()
     assert f16_err > 10 * (y3 - ref).abs().max().item()      # the compensation is doing something
+
+
+@pytest.mark.parametrize("cout,act", [(128, 0), (64, 1), (128, 3)])
+def test_conv_compensated_planar_stats_and_activation(gpu_device, cout, act):
+    """The planar compensated 3x3 kernel (conv_x3p.inc): fused GroupNorm partial statistics of the stored values, the
+    epilogue activations, and the dispatch itself (the library names the kernel it runs)."""
+    import ctypes as C
+    from elvis_amd import ops
+    from elvis_amd._lib import ConvDesc, check, lib, ptr
+    g = torch.Generator().manual_seed(31)
+    n, cin, h, w = 2, 96, 27, 45
+    x = torch.randn(n, cin, h, w, generator=g) * 2.0
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g)
+    conv = ops.PackedConv(wt, b, torch.float32, gpu_device, cin, x3=True)
+    d = ConvDesc()
+    d.dtype, d.n, d.h, d.w, d.ho, d.wo = ops.F32X3_CODE, n, h, w, h, w
+    d.cin, d.cin_pitch, d.cout, d.cout_pitch, d.ksize, d.stride, d.pad_before, d.act = cin, cin, cout, cout, 3, 1, 1, act
+    assert ops.conv_kernel_name(d).startswith("conv3x3_x3p_kernel<%d," % cout)
+    y = conv(_act(x, torch.float32, gpu_device), act=act, residual=_act(res, torch.float32, gpu_device), want_stats=True)
+    pre = F.conv2d(x, wt, b, padding=1)
+    ref = {0: pre, 1: F.gelu(pre), 3: F.relu(pre)}[act] + res
+    got = _nchw(y)
+    assert (got - ref).abs().max().item() < 2e-4
+    assert y.stats is not None
+    sums = torch.zeros((n, cout, 2), dtype=torch.float64, device=gpu_device)
+    check(lib().elvis_gn_partials_to_sums(ptr(y.stats), y.stats.shape[0] // n, n, cout, ptr(sums), cout, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+    assert torch.allclose(sums.cpu()[:, :, 0], got.double().sum((2, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(sums.cpu()[:, :, 1], (got.double() ** 2).sum((2, 3)), rtol=1e-6, atol=1e-3)
+
+
+def test_conv_compensated_operand_range(gpu_device):
+    """The documented operand limit of ELVIS_F32X3 (elvis_amd.h): the hi part of the hi + lo split is an f16, so an
+    activation or weight with |v| >= 65504 makes the products non-finite.  In range (here |x| up to 6e4) the result is
+    fp32-grade; out of range it is NOT silently wrong - it is inf / NaN."""
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(33)
+    cin, cout, h, w = 64, 64, 16, 32
+    x = torch.randn(1, cin, h, w, generator=g)
+    x[0, 3, 5, 7] = 6.0e4
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    conv = ops.PackedConv(wt, None, torch.float32, gpu_device, cin, x3=True)
+    y = _nchw(conv(_act(x, torch.float32, gpu_device)))
+    ref = F.conv2d(x.double(), wt.double(), padding=1).float()
+    # (the lo part of a small weight is an f16 subnormal - 6e-8 absolute - which a 6e4 activation scales up to ~2e-3)
+    assert torch.isfinite(y).all() and ((y - ref).abs() / (ref.abs() + 1.0)).max().item() < 1e-3
+    x[0, 3, 5, 7] = 1.0e5
+    y = _nchw(conv(_act(x, torch.float32, gpu_device)))
+    assert not torch.isfinite(y[0, :, 4:7, 6:9]).all()
 
 
 def test_upconv_compensated_f16(gpu_device):

@@ -68,7 +68,7 @@ def test_dcnv2_tile_kernel_eight_groups(gpu_device):
     assert (got - ref).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("dtype,lsb", [(torch.float32, 1), (torch.float16, 3)])
+@pytest.mark.parametrize("dtype,lsb", [(torch.float32, 1), (torch.float16, 2)])   # f16 measured: 1 LSB (bench line slots.dct.parity)
 def test_dcn_restorer_vs_oracle(gpu_device, dtype, lsb):
     from elvis_amd.restorers import DCNRestorer
     from elvis_amd.weights import DCNRestorerConfig, make_dcn_weights
@@ -86,7 +86,7 @@ def test_dcn_restorer_vs_oracle(gpu_device, dtype, lsb):
         assert (diff > 0).mean() < 1e-3      # rounding ties only
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.float16, 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.float16, 4e-3)])   # f16 measured: 1.9e-3 (bench line slots.blur.parity)
 def test_swin_deblur_vs_oracle(gpu_device, dtype, tol):
     from elvis_amd.restorers import SwinDeblur
     from elvis_amd.weights import SwinDeblurConfig, make_deblur_weights
