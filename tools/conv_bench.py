@@ -20,6 +20,10 @@ SHAPES = {  # name: (cin, cin2, cout, h, w, k, upsample)
     "lin192x576": (192, 0, 576, 320, 512, 1, False),
     "lin768x192": (768, 0, 192, 320, 512, 1, False),
     "lin192x192": (192, 0, 192, 320, 512, 1, False),
+    # sub-pixel form of "nearest 2x + 3x3" (ops.PackedUpConv: four 2x2 parity convs, kernel <half,128,256,8,false,2,false>)
+    "sub_up256_1080p": (256, 0, 256, 540, 960, 3, "sub"),
+    "sub_up512_540p": (512, 0, 512, 270, 480, 3, "sub"),
+    "unet320_160x256": (320, 0, 320, 160, 256, 3, False),   # 64-channel tile, 8-row form with --prologue
 }
 
 def main():
@@ -41,6 +45,23 @@ def main():
             continue
         wt = torch.randn(co, c1 + c2, k, k, generator=g) / math.sqrt((c1 + c2) * k * k)
         bias_h = torch.randn(co, generator=g)
+        if ups == "sub":
+            up = ops.PackedUpConv(wt, bias_h, dt, dev, c1)
+            x = ops.Act(torch.randn((a.n, h, w, c1), device=dev, dtype=dt), c1)
+            up(x, want_stats=a.stats)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(a.iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                up(x, want_stats=a.stats)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            fl = 2.0 * 16 * c1 * co * h * w * a.n     # executed: 16 taps per low-res pixel
+            t = sorted(ts)[len(ts) // 2]
+            print(f"{name:22s} {a.dtype} sub-pixel st={int(a.stats)}  {t:8.3f} ms  {fl / t / 1e9:8.1f} TFLOP/s executed  ({fl / 1e9:.0f} GFLOP)", flush=True)
+            continue
         conv = ops.PackedConv(wt, bias_h, dt, dev, c1, c2, x3=a.x3)
         x = ops.Act(torch.randn((a.n, h, w, c1), device=dev, dtype=dt), c1)
         x2 = ops.Act(torch.randn((a.n, h, w, c2), device=dev, dtype=dt), c2) if c2 else None
