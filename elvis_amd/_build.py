@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIBPATH = os.path.join(LIBDIR, "libelvis_amd.so")
-SOURCES = ["conv.hip", "conv_f32.hip", "dcn.hip", "api.hip", "glue.hip", "misc.hip", "norm.hip", "attn.hip", "degrade.hip"]   # slowest first
+SOURCES = ["conv.hip", "conv_f32.hip", "dcn.hip", "swin.hip", "api.hip", "glue.hip", "misc.hip", "norm.hip", "attn.hip", "degrade.hip"]   # slowest first
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
          "-ffp-contract=off"]  # bit-exact glue: no implicit FMA contraction (explicit fmaf where wanted)

@@ -57,6 +57,10 @@ SIGNATURES = {
     "elvis_groupnorm_affine": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "elvis_affine_act": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "elvis_layernorm": [vp, vp, i32, i64, i32, i32, i32, vp, vp, f32, vp],
+    "elvis_swin_packed_bytes": [i32, i32, i32],
+    "elvis_swin_pack_weights": [vp, vp, vp, i32, i32, i32, vp],
+    "elvis_swin_mlp": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp],
+    "elvis_swin_ln_linear": [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp],
     "elvis_window_attention": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, vp],
     "elvis_bicubic_upsample": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "elvis_vq_nearest": [vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
@@ -98,6 +102,7 @@ def lib() -> C.CDLL:
         handle.elvis_last_error.restype = C.c_char_p
         handle.elvis_conv_packed_weight_bytes.restype = C.c_size_t
         handle.elvis_groupnorm_workspace_floats.restype = C.c_size_t
+        handle.elvis_swin_packed_bytes.restype = C.c_size_t
         if handle.elvis_abi_version() != 1:
             raise RuntimeError("libelvis_amd.so ABI version mismatch")
         _lib = handle

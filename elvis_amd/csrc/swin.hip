@@ -1,0 +1,350 @@
+// Fused per-token blocks of the Swin layers (SinSR Swin-UNet, ELVIS v2 Blur deblurrer), f16 storage, fp32 accumulate:
+//
+//   MLP    : out = x + fc2( GELU( fc1( LayerNorm(x) ) ) )          (one launch instead of LN, fc1, fc2: the 4C-wide hidden
+//                                                                   tensor never leaves the CU - it was written and read
+//                                                                   back through HBM, 10 C bytes per token of 17 C)
+//   LINEAR : out = W . LayerNorm(x) + b                             (LN fused into the qkv projection)
+//
+// A workgroup (8 waves) owns 128*PXT consecutive tokens; a wave owns 16*PXT of them and keeps their C channels in
+// registers for the whole kernel as MFMA B fragments (token = column): LayerNorm is two register passes plus two
+// cross-lane adds, the normalised tile never touches memory.  The first GEMM's weights stream through LDS in chunks of
+// 64 output rows (LDS-DMA, two stages, issued one chunk ahead): S = W1[chunk] . xn is a [64 x 16*PXT] accumulator
+// tile per wave.  MLP: bias + erf-GELU in registers, and the accumulator tile IS the next MFMA's B operand - lane
+// (token, q) of a 16x16x32 C tile holds rows 4q..4q+3, so two stacked tiles give it eight k values; which eight is a
+// permutation of k that is applied to fc2's packed columns at load time (a sum does not care about its order).  The
+// second GEMM accumulates out[C x 16*PXT] over all hidden chunks in registers; the epilogue adds bias and the residual
+// and stores.  Output rows are permuted at packing time (as in the conv kernels) so that a lane owns 16 contiguous
+// channels of a token: 16-byte stores and residual loads.
+// Matrix work per MFMA-LDS byte is low here (a weight fragment feeds PXT MFMAs), so the kernel is paced by the GELU's
+// VALU and the weight stream, not by HBM: ~55 % matrix-pipe busy at C = 192 against the unfused chain's HBM-bound ~10 %.
+#include "common.h"
+#include <mutex>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct SwinArgs {
+    const half_t* x;      // [M, x_pitch]
+    half_t* out;          // [M, out_pitch]
+    const half_t* w;      // packed weights: per chunk [W1 chunk | W2 chunk]
+    const float* b1;      // [n1]
+    const float* b2;      // [C] (MLP)
+    const float* gamma;   // [C]
+    const float* beta;    // [C]
+    long long M;
+    int x_pitch, out_pitch;
+    int n1;               // fc1 outputs = hidden (MLP) or the projection's outputs (LINEAR); multiple of 64
+    float eps;
+};
+
+__device__ __forceinline__ int srow_off(int row, int q) { return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4); }
+template <typename F> __device__ __forceinline__ F lds_frag16(const char* p) {
+    return *reinterpret_cast<const F*>(__builtin_assume_aligned(p, 16));
+}
+
+template <int C, int PXT, bool MLP>
+__global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
+    constexpr int KB = C / 32;                          // 32-channel k blocks of the first GEMM
+    constexpr int CT = C / 16;                          // 16-row output tiles of the second GEMM
+    constexpr int W1B = KB * 4096;                      // one chunk of W1: [KB][64 rows][64 B]
+    constexpr int W2B = MLP ? 2 * C * 64 : 0;           // one chunk of W2: [2 k blocks][C rows][64 B]
+    constexpr int STAGE = W1B + W2B;
+    constexpr int PIECES = STAGE / 16 / 512;            // LDS-DMA pieces per thread per stage
+    static_assert(C % 64 == 0 && (STAGE / 16) % 512 == 0 && 2 * STAGE <= 160 * 1024, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const long long tok0 = ((long long)blockIdx.x * 8 + wave) * (16 * PXT);
+    const int nchunks = p.n1 / 64;
+
+    // ---- weight stream: stage s <- chunk hc, linear copy with the row swizzle on the per-lane SOURCE offset
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);
+    int src_off[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int c = tid + i * 512;
+        src_off[i] = srow_off(c >> 2, c & 3);
+    }
+    auto w_issue = [&](int hc, int s) {
+        hc = hc < nchunks ? hc : nchunks - 1;           // the chunk after the last re-loads it (never read): uniform vmcnt
+        const char* base = (const char*)p.w + (long long)hc * STAGE;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            unsigned keep;
+            const unsigned dst = lds_base + (unsigned)(s * STAGE + (i * 512 + wave_u * 64) * 16);
+            const char* src = base + src_off[i];
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    w_issue(0, 0);
+
+    // ---- the wave's tokens: load (B-fragment shaped), LayerNorm in registers, pack to f16
+    half8 xb[PXT][KB];
+    {
+        float mean[PXT], rstd[PXT];
+#pragma unroll
+        for (int t = 0; t < PXT; ++t) {
+            const long long tok = tok0 + 16 * t + lr;
+            const half_t* src = p.x + (tok < p.M ? tok : 0) * p.x_pitch + 8 * lq;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                xb[t][k] = *reinterpret_cast<const half8*>(src + 32 * k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xb[t][k][e];
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            mean[t] = s / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)xb[t][k][e] - mean[t];
+                    q = fmaf(d, d, q);
+                }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            rstd[t] = 1.0f / sqrtf(q / (float)C + p.eps);
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const float4v g0 = *reinterpret_cast<const float4v*>(p.gamma + 32 * k + 8 * lq), g1 = *reinterpret_cast<const float4v*>(p.gamma + 32 * k + 8 * lq + 4);
+            const float4v h0 = *reinterpret_cast<const float4v*>(p.beta + 32 * k + 8 * lq), h1 = *reinterpret_cast<const float4v*>(p.beta + 32 * k + 8 * lq + 4);
+#pragma unroll
+            for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = e < 4 ? g0[e & 3] : g1[e & 3], h = e < 4 ? h0[e & 3] : h1[e & 3];
+                    xb[t][k][e] = (half_t)(((float)xb[t][k][e] - mean[t]) * rstd[t] * g + h);
+                }
+        }
+    }
+
+    float4v acc[MLP ? CT : 1][PXT];
+    if constexpr (MLP) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) acc[c][t] = (float4v){0.f, 0.f, 0.f, 0.f};
+    }
+    const int a_off = srow_off(lr, lq);
+
+    for (int hc = 0; hc < nchunks; ++hc) {
+        const int s = hc & 1;
+        // chunk hc has landed (this thread's pieces: the only DMAs in flight), and everyone is past chunk hc-1's reads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        w_issue(hc + 1, s ^ 1);
+        const char* w1 = smem + s * STAGE + a_off;
+        float4v S[4][PXT];
+        // bias of this chunk's 64 rows: lane's rows are 16 i + 4 lq + r (MLP) or channels 16 lq + 4 i + r (LINEAR)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4v b = *reinterpret_cast<const float4v*>(p.b1 + 64 * hc + (MLP ? 16 * i + 4 * lq : 16 * lq + 4 * i));
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) S[i][t] = b;
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            half8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = lds_frag16<half8>(w1 + k * 4096 + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) S[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xb[t][k], S[i][t], 0, 0, 0);
+        }
+        if constexpr (MLP) {
+            // GELU, then two stacked 16-row tiles are one 32-deep B fragment: element j of lane (token, q) is hidden row
+            // 32 m + 16 (j >> 2) + 4 q + (j & 3) of the chunk - fc2's columns are packed in that order
+            half8 H[PXT][2];
+#pragma unroll
+            for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) H[t][m][j] = (half_t)gelu_erf_f(S[2 * m + (j >> 2)][t][j & 3]);
+            const char* w2 = smem + s * STAGE + W1B + a_off;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const half8 a = lds_frag16<half8>(w2 + m * (C * 64) + c * 1024);
+#pragma unroll
+                    for (int t = 0; t < PXT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, H[t][m], acc[c][t], 0, 0, 0);
+                }
+        } else {
+            // LINEAR: the chunk's 64 output channels of each token: the lane's 16 contiguous ones as two 16-byte stores
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) {
+                const long long tok = tok0 + 16 * t + lr;
+                if (tok < p.M) {
+                    half8 lo, hi;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        lo[r] = (half_t)S[0][t][r]; lo[4 + r] = (half_t)S[1][t][r];
+                        hi[r] = (half_t)S[2][t][r]; hi[4 + r] = (half_t)S[3][t][r];
+                    }
+                    half_t* dst = p.out + tok * p.out_pitch + 64 * hc + 16 * lq;
+                    *reinterpret_cast<half8*>(dst) = lo;
+                    *reinterpret_cast<half8*>(dst + 8) = hi;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMA must have landed before the workgroup's LDS is released
+    if constexpr (MLP) {
+        // out = x + b2 + acc: output tile c = 4 g + i, accumulator row 4 lq + r  <->  channel 64 g + 16 lq + 4 i + r
+#pragma unroll
+        for (int t = 0; t < PXT; ++t) {
+            const long long tok = tok0 + 16 * t + lr;
+            const long long tc = tok < p.M ? tok : 0;
+#pragma unroll
+            for (int g = 0; g < C / 64; ++g) {
+                const int ch = 64 * g + 16 * lq;
+                const half8 r0 = *reinterpret_cast<const half8*>(p.x + tc * p.x_pitch + ch), r1 = *reinterpret_cast<const half8*>(p.x + tc * p.x_pitch + ch + 8);
+                half8 lo, hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4v b = *reinterpret_cast<const float4v*>(p.b2 + ch + 4 * i);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float res = (float)(i < 2 ? r0[4 * i + r] : r1[4 * (i - 2) + r]);
+                        const half_t v = (half_t)(acc[4 * g + i][t][r] + b[r] + res);
+                        if (i < 2) lo[4 * i + r] = v; else hi[4 * (i - 2) + r] = v;
+                    }
+                }
+                if (tok < p.M) {
+                    half_t* dst = p.out + tok * p.out_pitch + ch;
+                    *reinterpret_cast<half8*>(dst) = lo;
+                    *reinterpret_cast<half8*>(dst + 8) = hi;
+                }
+            }
+        }
+    }
+}
+
+template <int C, int PXT, bool MLP> int launch_swin(const SwinArgs& a, hipStream_t stream) {
+    constexpr int STAGE = (C / 32) * 4096 + (MLP ? 2 * C * 64 : 0);
+    const size_t lds = 2 * (size_t)STAGE;
+    {
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        std::lock_guard<std::mutex> guard(mu);
+        if (!attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)swin_fused_kernel<C, PXT, MLP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) {
+                elvis_set_error("elvis_swin: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+                return ELVIS_E_RUNTIME;
+            }
+            attr_set[dev] = true;
+        }
+    }
+    const long long per = 128LL * PXT;
+    const long long blocks = (a.M + per - 1) / per;
+    ELVIS_REQUIRE(blocks < 0x7fffffffLL, "elvis_swin: grid too large");
+    hipLaunchKernelGGL((swin_fused_kernel<C, PXT, MLP>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    ELVIS_CHECK_LAUNCH("elvis_swin");
+    return ELVIS_OK;
+}
+
+template <bool MLP> int dispatch_swin(int c, const SwinArgs& a, hipStream_t stream) {
+    switch (c) {
+        case 64: return launch_swin<64, 2, MLP>(a, stream);
+        case 128: return launch_swin<128, 2, MLP>(a, stream);
+        case 192: return launch_swin<192, 2, MLP>(a, stream);
+        case 256: return launch_swin<256, 1, MLP>(a, stream);    // 128 accumulator registers at two tokens tiles: one
+        default: break;
+    }
+    elvis_set_error("elvis_swin: channels must be 64, 128, 192 or 256 (got %d)", c);
+    return ELVIS_E_INVALID;
+}
+
+static int check_common(const void* x, const void* out, const void* w, const float* gamma, const float* beta, long long tokens, int c,
+                        int x_pitch, int out_pitch, int n_out) {
+    ELVIS_REQUIRE(x && out && w && gamma && beta, "elvis_swin: null pointer");
+    ELVIS_REQUIRE(tokens > 0 && c > 0 && c % 64 == 0 && x_pitch >= c && x_pitch % 8 == 0 && out_pitch >= n_out && out_pitch % 8 == 0,
+                  "elvis_swin: bad shape (tokens %lld, c %d, pitches %d / %d)", tokens, c, x_pitch, out_pitch);
+    ELVIS_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "elvis_swin: pointers must be 16-byte aligned");
+    return ELVIS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t elvis_swin_packed_bytes(int c, int n1, int mlp) {
+    if (c <= 0 || c % 64 || n1 <= 0 || n1 % 64) return 0;
+    return (size_t)(n1 / 64) * ((size_t)(c / 32) * 4096 + (mlp ? 2 * (size_t)c * 64 : 0));
+}
+
+// OIHW-style fp32 weights -> the kernels' packed f16 stream: per 64-row chunk hc of the first matrix
+//   [k block][64 rows][32 halfs] of W1 (rows in natural order for the MLP, in the 16-contiguous-channels-per-lane order
+//   for LINEAR), then for the MLP [2 k blocks][C rows][32 halfs] of W2's columns 64 hc .. 64 hc + 63 (rows in the
+//   16-contiguous order, columns in the accumulator-as-operand order, swin_fused_kernel).
+__global__ void swin_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, half_t* __restrict__ out, int c, int n1,
+                                 int mlp, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kb_n = c / 32;
+    const long long stage = (long long)kb_n * 2048 + (mlp ? 2LL * c * 32 : 0);    // halfs per chunk
+    const int hc = (int)(i / stage);
+    long long r = i - (long long)hc * stage;
+    float v;
+    if (r < (long long)kb_n * 2048) {
+        const int kk = (int)(r & 31), row = (int)((r >> 5) & 63), kb = (int)(r >> 11);
+        int o = 64 * hc + row;                                        // MLP: hidden row, natural order
+        if (!mlp) {
+            const int i4 = row >> 4, q = (row >> 2) & 3, rr = row & 3;
+            o = 64 * hc + 16 * q + 4 * i4 + rr;
+        }
+        v = w1[(long long)o * c + 32 * kb + kk];
+    } else {
+        r -= (long long)kb_n * 2048;
+        const int kk = (int)(r & 31);
+        const int row = (int)((r >> 5) % c), m = (int)((r >> 5) / c);
+        const int g = row >> 6, i4 = (row >> 4) & 3, q = (row >> 2) & 3, rr = row & 3;
+        const int co = 64 * g + 16 * q + 4 * i4 + rr;
+        const int lqk = kk >> 3, j = kk & 7;
+        const int hid = 64 * hc + 32 * m + 16 * (j >> 2) + 4 * lqk + (j & 3);
+        v = w2[(long long)co * n1 + hid];
+    }
+    out[i] = (half_t)v;
+}
+
+extern "C" int elvis_swin_pack_weights(const float* w1, const float* w2, void* packed, int c, int n1, int mlp, elvis_stream_t stream) {
+    ELVIS_REQUIRE(w1 && packed && (!mlp || w2), "elvis_swin_pack_weights: null pointer");
+    const size_t bytes = elvis_swin_packed_bytes(c, n1, mlp);
+    ELVIS_REQUIRE(bytes > 0, "elvis_swin_pack_weights: c (%d) and n1 (%d) must be positive multiples of 64", c, n1);
+    const long long total = (long long)(bytes / 2);
+    hipLaunchKernelGGL(swin_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, w2, (half_t*)packed, c, n1,
+                       mlp, total);
+    ELVIS_CHECK_LAUNCH("elvis_swin_pack_weights");
+    return ELVIS_OK;
+}
+
+extern "C" int elvis_swin_mlp(const void* x, void* out, const void* packed, const float* b1, const float* b2, const float* gamma,
+                              const float* beta, long long tokens, int c, int hidden, int x_pitch, int out_pitch, float eps,
+                              elvis_stream_t stream) {
+    int rc = check_common(x, out, packed, gamma, beta, tokens, c, x_pitch, out_pitch, c);
+    if (rc) return rc;
+    ELVIS_REQUIRE(b1 && b2 && hidden > 0 && hidden % 64 == 0, "elvis_swin_mlp: hidden (%d) must be a positive multiple of 64", hidden);
+    ELVIS_REQUIRE((((uintptr_t)b1 | (uintptr_t)b2) & 15) == 0, "elvis_swin_mlp: biases must be 16-byte aligned");
+    SwinArgs a{(const half_t*)x, (half_t*)out, (const half_t*)packed, b1, b2, gamma, beta, tokens, x_pitch, out_pitch, hidden, eps};
+    return dispatch_swin<true>(c, a, (hipStream_t)stream);
+}
+
+extern "C" int elvis_swin_ln_linear(const void* x, void* out, const void* packed, const float* bias, const float* gamma, const float* beta,
+                                    long long tokens, int c, int n_out, int x_pitch, int out_pitch, float eps, elvis_stream_t stream) {
+    int rc = check_common(x, out, packed, gamma, beta, tokens, c, x_pitch, out_pitch, n_out);
+    if (rc) return rc;
+    ELVIS_REQUIRE(bias && n_out > 0 && n_out % 64 == 0 && (((uintptr_t)bias) & 15) == 0, "elvis_swin_ln_linear: n_out (%d) must be a positive multiple of 64, bias 16-byte aligned", n_out);
+    SwinArgs a{(const half_t*)x, (half_t*)out, (const half_t*)packed, bias, nullptr, gamma, beta, tokens, x_pitch, out_pitch, n_out, eps};
+    return dispatch_swin<false>(c, a, (hipStream_t)stream);
+}

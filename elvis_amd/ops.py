@@ -489,6 +489,54 @@ def window_attention(qkv: Act, heads, head_dim, ws, shift, bias_table, scale) ->
     return out
 
 
+SWIN_FUSED_CHANNELS = (64, 128, 192, 256)
+
+
+class SwinFused:
+    """LayerNorm + one or two token-wise linear layers in ONE kernel (csrc/swin.hip), f16 tensors:
+
+      SwinFused(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b)  ->  __call__(x) = x + fc2(GELU(fc1(LN(x))))   (the Swin MLP)
+      SwinFused(norm_w, norm_b, w, b)                        ->  __call__(x) = w . LN(x) + b               (LN + qkv)
+
+    `supported(c, n1)` says whether a shape has a fused kernel (channels 64 / 128 / 192 / 256, outputs a multiple of 64);
+    callers keep the separate layernorm + 1x1-conv kernels for everything else (fp32 / compensated modes too)."""
+
+    @staticmethod
+    def supported(dtype, c: int, n1: int) -> bool:
+        return dtype == torch.float16 and c in SWIN_FUSED_CHANNELS and n1 % 64 == 0
+
+    def __init__(self, norm_w, norm_b, w1, b1, w2=None, b2=None, *, device, eps: float = 1e-5):
+        n1, c = w1.shape[0], w1.shape[1]
+        if not self.supported(torch.float16, c, n1):
+            raise ValueError(f"no fused Swin kernel for {c} channels / {n1} outputs")
+        self.c, self.n1, self.mlp, self.eps, self.device = c, n1, w2 is not None, float(eps), device
+        f32 = dict(device=device, dtype=torch.float32)
+        w1d = w1.reshape(n1, c).to(**f32).contiguous()
+        w2d = w2.reshape(c, n1).to(**f32).contiguous() if self.mlp else None
+        self.packed = torch.empty(lib().elvis_swin_packed_bytes(c, n1, int(self.mlp)), dtype=torch.uint8, device=device)
+        check(lib().elvis_swin_pack_weights(ptr(w1d), ptr(w2d), ptr(self.packed), c, n1, int(self.mlp), _s(self.packed)), device)
+        torch.cuda.current_stream(device).synchronize()   # w1d / w2d may be freed after return
+        self.b1 = b1.to(**f32).contiguous()
+        self.b2 = b2.to(**f32).contiguous() if self.mlp else None
+        self.gamma, self.beta = norm_w.to(**f32).contiguous(), norm_b.to(**f32).contiguous()
+
+    def __call__(self, x: Act) -> Act:
+        if x.c != self.c or x.t.dtype != torch.float16:
+            raise ValueError(f"fused Swin block: expected f16 with {self.c} channels, got {x.t.dtype} with {x.c}")
+        tokens = x.n * x.h * x.w
+        cout = self.c if self.mlp else self.n1
+        out = new_act(x.n, x.h, x.w, cout, torch.float16, x.t.device, zero=False)
+        if self.mlp:
+            with _Timed("swin_mlp", "mfma", 4.0 * self.c * self.n1 * tokens):
+                check(lib().elvis_swin_mlp(ptr(x.t), ptr(out.t), ptr(self.packed), ptr(self.b1), ptr(self.b2), ptr(self.gamma),
+                                           ptr(self.beta), tokens, self.c, self.n1, x.pitch, out.pitch, self.eps, _s(x.t)), x.t.device)
+        else:
+            with _Timed("swin_ln_linear", "hbm", 2.0 * (self.c + self.n1) * tokens):
+                check(lib().elvis_swin_ln_linear(ptr(x.t), ptr(out.t), ptr(self.packed), ptr(self.b1), ptr(self.gamma), ptr(self.beta),
+                                                 tokens, self.c, self.n1, x.pitch, out.pitch, self.eps, _s(x.t)), x.t.device)
+        return out
+
+
 def bicubic_upsample(x: Act, sf: int) -> Act:
     out = new_act(x.n, x.h * sf, x.w * sf, x.c, x.t.dtype, x.t.device, zero=False)
     check(lib().elvis_bicubic_upsample(ptr(x.t), ptr(out.t), x.dtype_code, x.n, x.h, x.w, x.c, x.pitch, out.pitch, sf,

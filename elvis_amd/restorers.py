@@ -85,11 +85,17 @@ class _SwinStage:
         self.cfg, self.ch, self.heads = cfg, ch, ch // cfg.head_dim
         f32 = dict(device=device, dtype=torch.float32)
         self.blocks = []
+        from .sinsr import _SWIN_FUSE
+        fuse = _SWIN_FUSE and ops.SwinFused.supported(dtype, ch, 3 * ch) and ops.SwinFused.supported(dtype, ch, cfg.mlp_ratio * ch)
         for i in range(nblocks):
             b = f"{prefix}.{i}"
             lin = lambda n: PackedConv(sd[n + ".weight"][:, :, None, None], sd[n + ".bias"], dtype, device,
                                        sd[n + ".weight"].shape[1])
+            w = lambda n: sd[b + n]
             self.blocks.append(dict(
+                qkv_f=ops.SwinFused(w(".norm1.weight"), w(".norm1.bias"), w(".attn.qkv.weight"), w(".attn.qkv.bias"), device=device) if fuse else None,
+                mlp_f=ops.SwinFused(w(".norm2.weight"), w(".norm2.bias"), w(".mlp.fc1.weight"), w(".mlp.fc1.bias"),
+                                    w(".mlp.fc2.weight"), w(".mlp.fc2.bias"), device=device) if fuse else None,
                 n1=(sd[b + ".norm1.weight"].to(**f32), sd[b + ".norm1.bias"].to(**f32)),
                 n2=(sd[b + ".norm2.weight"].to(**f32), sd[b + ".norm2.bias"].to(**f32)),
                 qkv=lin(b + ".attn.qkv"), proj=lin(b + ".attn.proj"), fc1=lin(b + ".mlp.fc1"), fc2=lin(b + ".mlp.fc2"),
@@ -99,14 +105,17 @@ class _SwinStage:
     def __call__(self, y: Act) -> Act:
         cfg = self.cfg
         for b in self.blocks:
-            t = ops.layernorm(y, *b["n1"])
-            qkv = b["qkv"](t)
+            qkv = b["qkv_f"](y) if b["qkv_f"] is not None else b["qkv"](ops.layernorm(y, *b["n1"]))
             a = ops.window_attention(qkv, self.heads, cfg.head_dim, cfg.window_size, b["shift"], b["table"],
                                      cfg.head_dim ** -0.5)
+            del qkv
             y = b["proj"](a, residual=y)
-            t = ops.layernorm(y, *b["n2"])
-            t = b["fc1"](t, act=GELU)
-            y = b["fc2"](t, residual=y)
+            if b["mlp_f"] is not None:
+                y = b["mlp_f"](y)
+            else:
+                t = ops.layernorm(y, *b["n2"])
+                t = b["fc1"](t, act=GELU)
+                y = b["fc2"](t, residual=y)
         return y
 
 

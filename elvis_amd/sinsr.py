@@ -21,6 +21,10 @@ from .ops import Act, PackedConv, PackedUpConv
 from .weights import SinSRConfig, frame_noise, make_sinsr_weights, timestep_embedding, unet_layout
 
 
+import os as _os_mod
+_SWIN_FUSE = not _os_mod.environ.get("ELVIS_NO_SWIN_FUSE")   # A/B switch, read once at import
+
+
 class _GN:
     def __init__(self, sd, p, device):
         self.gamma = sd[p + ".weight"].to(device=device, dtype=torch.float32).contiguous()
@@ -122,9 +126,15 @@ class _SwinLayer:
         self.embed = _conv(sd, p + ".patch_embed.proj", dtype, device, ch)
         self.embed_norm = (sd[p + ".patch_embed.norm.weight"].to(**f32), sd[p + ".patch_embed.norm.bias"].to(**f32))
         self.blocks = []
+        fuse = _SWIN_FUSE and ops.SwinFused.supported(dtype, E, 3 * E) and ops.SwinFused.supported(dtype, E, cfg.mlp_ratio * E)
         for d in range(cfg.swin_depth):
             b = f"{p}.blocks.{d}"
+            w = lambda n: sd[b + n]
             self.blocks.append(dict(
+                # f16: LayerNorm + qkv in one kernel, LayerNorm + fc1 + GELU + fc2 + residual in one kernel (csrc/swin.hip)
+                qkv_f=ops.SwinFused(w(".norm1.weight"), w(".norm1.bias"), w(".attn.qkv.weight"), w(".attn.qkv.bias"), device=device) if fuse else None,
+                mlp_f=ops.SwinFused(w(".norm2.weight"), w(".norm2.bias"), w(".mlp.fc1.weight"), w(".mlp.fc1.bias"),
+                                    w(".mlp.fc2.weight"), w(".mlp.fc2.bias"), device=device) if fuse else None,
                 n1=(sd[b + ".norm1.weight"].to(**f32), sd[b + ".norm1.bias"].to(**f32)),
                 n2=(sd[b + ".norm2.weight"].to(**f32), sd[b + ".norm2.bias"].to(**f32)),
                 qkv=_linear(sd, b + ".attn.qkv", dtype, device),
@@ -140,15 +150,17 @@ class _SwinLayer:
         y = self.embed(x)
         ops.layernorm(y, *self.embed_norm, out=y)
         for b in self.blocks:
-            t = ops.layernorm(y, *b["n1"])
-            qkv = b["qkv"](t)
+            qkv = b["qkv_f"](y) if b["qkv_f"] is not None else b["qkv"](ops.layernorm(y, *b["n1"]))
             a = ops.window_attention(qkv, cfg.heads, cfg.num_head_channels, cfg.window_size, b["shift"], b["table"],
                                      cfg.num_head_channels ** -0.5)
             del qkv
             y = b["proj"](a, residual=y)
-            t = ops.layernorm(y, *b["n2"])
-            t = b["fc1"](t, act=1)
-            y = b["fc2"](t, residual=y)
+            if b["mlp_f"] is not None:
+                y = b["mlp_f"](y)
+            else:
+                t = ops.layernorm(y, *b["n2"])
+                t = b["fc1"](t, act=1)
+                y = b["fc2"](t, residual=y)
         return self.unembed(y)
 
 

@@ -216,6 +216,22 @@ int elvis_affine_act(const void* x, void* y, int dtype, int n, int hw, int c, in
 int elvis_layernorm(const void* x, void* y, int dtype, long long tokens, int c, int pitch_in,
                     int pitch_out, const float* gamma, const float* beta, float eps, elvis_stream_t stream);
 
+/* Fused per-token blocks of a Swin layer, f16 tensors, fp32 accumulate (csrc/swin.hip; model slots a5 / a7 of SURVEY.md 8a:
+ * the reference delegates these layers to absent pip packages, there is no reference file:line for them).
+ *   elvis_swin_mlp       : out = x + fc2(GELU(fc1(LayerNorm(x))))   - one launch, the hidden tensor never reaches HBM
+ *   elvis_swin_ln_linear : out = W . LayerNorm(x) + bias            - LayerNorm fused into a projection (qkv)
+ * c (channels) in {64, 128, 192, 256}; hidden / n_out multiples of 64; x[tokens, x_pitch], out[tokens, out_pitch] f16;
+ * biases, gamma, beta f32; all pointers 16-byte aligned.  Weights are packed once by elvis_swin_pack_weights from
+ * row-major f32 matrices w1[n1, c] (fc1 or the projection) and, for the MLP, w2[c, n1] (fc2) into
+ * elvis_swin_packed_bytes(c, n1, mlp) bytes. */
+size_t elvis_swin_packed_bytes(int c, int n1, int mlp);
+int elvis_swin_pack_weights(const float* w1, const float* w2, void* packed, int c, int n1, int mlp, elvis_stream_t stream);
+int elvis_swin_mlp(const void* x, void* out, const void* packed, const float* b1, const float* b2, const float* gamma,
+                   const float* beta, long long tokens, int c, int hidden, int x_pitch, int out_pitch, float eps,
+                   elvis_stream_t stream);
+int elvis_swin_ln_linear(const void* x, void* out, const void* packed, const float* bias, const float* gamma, const float* beta,
+                         long long tokens, int c, int n_out, int x_pitch, int out_pitch, float eps, elvis_stream_t stream);
+
 /* Swin (shifted-)window attention on a token image qkv[n,h,w,3*E] (q|k|v, head-major inside
  * each), window ws, `shift` cyclic shift (0 or ws/2) with the standard region mask, relative
  * position bias table [(2ws-1)^2, heads] f32.  out[n,h,w,E] in image order (un-shifted). */

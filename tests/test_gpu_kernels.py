@@ -505,3 +505,45 @@ def test_conv_compensated_f16_fused_upsample(gpu_device):
     y = _nchw(conv(_act(x, torch.float32, gpu_device), upsample=True))
     ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
     assert (y - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("c,ratio,tokens_hw", [(64, 4, (3, 19, 23)), (128, 2, (1, 40, 33)), (192, 4, (2, 16, 40)), (256, 2, (1, 24, 24))])
+def test_swin_fused_mlp_and_ln_linear(gpu_device, c, ratio, tokens_hw):
+    """csrc/swin.hip: out = x + fc2(GELU(fc1(LN(x)))) and out = W.LN(x) + b in one kernel each, against an fp32 CPU
+    restatement (f16 storage of x, the normalised tokens, the weights and the hidden activations emulated) and against
+    the unfused kernel chain (layernorm + 1x1 convs).  Token counts that do not fill the last workgroup / wave."""
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(41)
+    n, h, w = tokens_hw
+    hid = ratio * c
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + torch.randn(n, 1, h, w, generator=g)
+    nw, nb = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    w1, b1 = torch.randn(hid, c, generator=g) / math.sqrt(c), torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(c, hid, generator=g) / math.sqrt(hid), torch.randn(c, generator=g) * 0.1
+    wq, bq = torch.randn(3 * c, c, generator=g) / math.sqrt(c), torch.randn(3 * c, generator=g) * 0.1
+    xa = _act(x, torch.float16, gpu_device)
+    q = lambda t: t.half().float()
+    xt = q(x).permute(0, 2, 3, 1)                                        # tokens last-dim channels
+    ln = q(F.layer_norm(xt, (c,), nw, nb, 1e-5))
+    ref_mlp = xt + F.linear(q(F.gelu(F.linear(ln, q(w1), b1))), q(w2), b2)
+    ref_qkv = F.linear(ln, q(wq), bq)
+
+    mlp = ops.SwinFused(nw, nb, w1, b1, w2, b2, device=gpu_device)
+    got = mlp(xa).t[..., :c].float().cpu()
+    assert (got - ref_mlp).abs().max().item() < 2e-2
+    lin = ops.SwinFused(nw, nb, wq, bq, device=gpu_device)
+    gq = lin(xa).t[..., :3 * c].float().cpu()
+    assert (gq - ref_qkv).abs().max().item() < 2e-2
+    # the unfused chain of product kernels
+    t = ops.layernorm(xa, nw.to(gpu_device), nb.to(gpu_device))
+    fc1 = ops.PackedConv(w1[:, :, None, None], b1, torch.float16, gpu_device, c)
+    fc2 = ops.PackedConv(w2[:, :, None, None], b2, torch.float16, gpu_device, hid)
+    chain = fc2(fc1(t, act=1), residual=xa).t[..., :c].float().cpu()
+    assert (got - chain).abs().max().item() < 2e-2
+    qk = ops.PackedConv(wq[:, :, None, None], bq, torch.float16, gpu_device, c)(t).t[..., :3 * c].float().cpu()
+    assert (gq - qk).abs().max().item() < 2e-2
+    # tighter, in rms: the fused kernels are as close to the fp32 restatement as the chain is
+    rms = lambda a, b: (a - b).pow(2).mean().sqrt().item()
+    assert rms(got, ref_mlp) < 1.5 * rms(chain, ref_mlp) + 1e-4 and rms(gq, ref_qkv) < 1.5 * rms(qk, ref_qkv) + 1e-4
+    with pytest.raises(ValueError):
+        ops.SwinFused(nw[:40], nb[:40], w1[:, :40], b1, device=gpu_device)
