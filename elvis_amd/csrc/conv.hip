@@ -6,7 +6,7 @@
 __attribute__((visibility("hidden"))) int elvis_conv_launch_f32_(const void* conv_args, int halo, int tco, int id, hipStream_t stream);
 // conv_f32.hip: the planar compensated form's weight packing (conv_x3p.inc)
 __attribute__((visibility("hidden"))) int elvis_conv_pack_x3p_(const float* w_oihw, void* packed, int cout, int ctot, int nkc, int n_co_tiles,
-                                                              int tco, hipStream_t stream);
+                                                              int tco, int taps, hipStream_t stream);
 
 // A/B switches of the experiment tools: read ONCE per process, never on the per-call path
 static bool no_halo() {
@@ -42,7 +42,7 @@ extern "C" int elvis_conv_pack_weights(const elvis_conv_desc* d, const float* w_
     conv_geom(d, &nkc1, &nkc, &co_pad);
     if (x3_planar_fmt(d)) {
         const int tco = choose_tile(d->cout).tco;
-        return elvis_conv_pack_x3p_(w_oihw, packed, d->cout, d->cin + d->cin2, nkc, co_pad / tco, tco, (hipStream_t)stream);
+        return elvis_conv_pack_x3p_(w_oihw, packed, d->cout, d->cin + d->cin2, nkc, co_pad / tco, tco, d->ksize * d->ksize, (hipStream_t)stream);
     }
     int KC = kc_elems(d->dtype);
     // with two inputs the packed K axis is [cin padded to nkc1*KC | cin2]; cin % KC == 0 is
@@ -89,7 +89,7 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
     if (halo_eligible(d) && !no_halo()) {
         const bool pro = d->ksize == 3 && d->prologue;
         if (x3_planar_run(d))
-            snprintf(buf, n, "conv3x3_x3p_kernel<%d,%d,%s,%s>", c.tco, halo_ty(d), pro ? "true" : "false", d->act ? "true" : "false");
+            snprintf(buf, n, "conv3x3_x3p_kernel<%d,%d,%d,%s,%s>", c.tco, halo_ty(d), d->ksize, pro ? "true" : "false", d->act ? "true" : "false");
         else if (d->dtype == ELVIS_F32X3 && c.tco >= 64)
             snprintf(buf, n, "conv3x3_halo_x3_kernel<%d,%d,%s,%d,%s>", c.tco, halo_ty(d), pro ? "true" : "false", d->ksize,
                      d->act ? "true" : "false");
@@ -139,7 +139,7 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.pad2x = subpix ? 1 - a.par_b : 0;
     a.s2d = s2d ? 1 : 0;
     a.istr = s2d ? 2 : 1;
-    a.nkc_c = s2d ? d->cin / 4 / 32 : 0x3fffffff;
+    a.nkc_c = s2d ? d->cin / 4 / kc_of(d) : 0x3fffffff;
     a.wfull = d->w;
     if (s2d) {   // the kernel sees the phase image: ho x wo pixels of 4C channels
         a.h = d->ho;

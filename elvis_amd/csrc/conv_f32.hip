@@ -18,10 +18,10 @@ __attribute__((visibility("hidden"))) int elvis_conv_launch_f32_(const void* con
 }
 
 __attribute__((visibility("hidden"))) int elvis_conv_pack_x3p_(const float* w_oihw, void* packed, int cout, int ctot, int nkc, int n_co_tiles,
-                                                              int tco, hipStream_t stream) {
-    const long long total = 9LL * nkc * n_co_tiles * 2 * tco * 32;
+                                                              int tco, int taps, hipStream_t stream) {
+    const long long total = (long long)taps * nkc * n_co_tiles * 2 * tco * 32;
     hipLaunchKernelGGL(pack_weights_x3p_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, (half_t*)packed,
-                       cout, ctot, nkc, n_co_tiles, tco, total);
+                       cout, ctot, nkc, n_co_tiles, tco, taps, total);
     ELVIS_CHECK_LAUNCH("elvis_conv_pack_weights(x3p)");
     return ELVIS_OK;
 }

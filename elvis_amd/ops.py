@@ -249,8 +249,8 @@ class PackedConv:
             ho = (lh + 2 * d.pad_before - self.ksize) // stride + 1
             wo = (lw + 2 * d.pad_before - self.ksize) // stride + 1
         d.ho, d.wo = ho, wo
-        if out is None:
-            out = new_act(x.n, ho, wo, self.cout, x.t.dtype, x.t.device)
+        if out is None:   # (the conv kernels write the pad channels themselves: no zero-fill pass)
+            out = new_act(x.n, ho, wo, self.cout, x.t.dtype, x.t.device, zero=False)
         d.cout, d.cout_pitch = self.cout, out.pitch
         pa = pb = None
         if prologue is not None:
@@ -341,7 +341,7 @@ class PackedUpConv:
         if x.t.dtype != self.par[0].dtype:
             raise ValueError(f"conv: weights are packed for {self.par[0].dtype}, got a {x.t.dtype} tensor")
         n, h, w = x.n, x.h, x.w
-        out = new_act(n, 2 * h, 2 * w, self.cout, x.t.dtype, x.t.device)
+        out = new_act(n, 2 * h, 2 * w, self.cout, x.t.dtype, x.t.device, zero=False)   # the four parities write every pixel, pads included
         stats = None
         for k, conv in enumerate(self.par):
             d = ConvDesc()
@@ -382,14 +382,21 @@ class PackedDownConv:
     an ho x wo image and a 2x2 conv with the re-indexed 3x3 taps runs on the halo-tile kernel
     (W[2ry+py][2rx+px] at channel (2py+px)*C + c, tap (ry, rx); 7 of the 16 phase/tap blocks are
     zero).  Same result as the strided conv in real arithmetic; 1.78x the MFMA work of the direct form,
-    at ~3.5x its rate on the generic strided kernel.  f16, C % 32 == 0, cout >= 64."""
+    at ~3.5x its rate on the generic strided kernel.  f16 (C % 32 == 0) or fp32 tensors on the compensated
+    f16 MFMA (ELVIS_F32X3, C % 16 == 0); cout >= 64."""
 
     S2D = 5   # ELVIS_CONV_S2D
 
+    @staticmethod
+    def supported(dtype, cin: int, cout: int, x3: bool = False) -> bool:
+        """f16 with whole 32-channel chunks, or fp32 tensors on the compensated f16 MFMA (16-channel chunks)."""
+        return cout >= 64 and ((dtype == torch.float16 and cin % 32 == 0) or (dtype == torch.float32 and x3 and cin % 16 == 0))
+
     def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int):
         cout, ctot, kh, kw = weight_oihw.shape
-        assert kh == 3 and kw == 3 and ctot == cin and cin % 32 == 0 and dtype == torch.float16
-        self.cin, self.cout, self.device = cin, cout, device
+        assert kh == 3 and kw == 3 and ctot == cin and self.supported(dtype, cin, cout, x3=True)
+        self.cin, self.cout, self.device, self.dtype = cin, cout, device, dtype
+        self.code = L.F16 if dtype == torch.float16 else F32X3_CODE
         w = weight_oihw.float()
         w4 = torch.zeros(cout, 4 * cin, 2, 2)
         for dy in range(3):
@@ -407,7 +414,7 @@ class PackedDownConv:
 
     def _desc(self, n, h, w, cin_pitch, cout_pitch):
         d = ConvDesc()
-        d.dtype = L.F16
+        d.dtype = self.code
         d.n, d.h, d.w, d.ho, d.wo = n, h, w, h // 2, w // 2
         d.cin, d.cin_pitch = 4 * self.cin, cin_pitch
         d.cout, d.cout_pitch = self.cout, cout_pitch
@@ -415,9 +422,9 @@ class PackedDownConv:
         return d
 
     def __call__(self, x: Act, want_stats: bool = False) -> Act:
-        if x.c != self.cin or x.h % 2 or x.w % 2 or x.t.dtype != torch.float16:
-            raise ValueError(f"downsample conv: expected f16, {self.cin} channels and even H, W; got {x.t.dtype}, {x.c}, {x.h}x{x.w}")
-        out = new_act(x.n, x.h // 2, x.w // 2, self.cout, x.t.dtype, x.t.device)
+        if x.c != self.cin or x.h % 2 or x.w % 2 or x.t.dtype != self.dtype:
+            raise ValueError(f"downsample conv: expected {self.dtype}, {self.cin} channels and even H, W; got {x.t.dtype}, {x.c}, {x.h}x{x.w}")
+        out = new_act(x.n, x.h // 2, x.w // 2, self.cout, x.t.dtype, x.t.device, zero=False)
         d = self._desc(x.n, x.h, x.w, x.pitch, out.pitch)
         tiles = lib().elvis_conv_stats_tiles(C.byref(d))
         stats = torch.empty((tiles, self.cout, 2), dtype=torch.float32, device=x.t.device) if want_stats and tiles > 0 else None

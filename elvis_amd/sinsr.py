@@ -36,16 +36,16 @@ def _conv(sd, p, dtype, device, cin, cin2=0) -> PackedConv:
 
 
 class _DownConv:
-    """The autoencoder's Downsample: pad (0,1,0,1) + 3x3 conv, stride 2.  f16 with whole 32-channel
-    chunks and even sizes: the space-to-depth form on the halo-tile kernel (ops.PackedDownConv, with
-    fused GroupNorm statistics); otherwise (fp32 mode, ELVIS_NO_S2D=1, odd sizes) the generic strided
-    kernel - same result to rounding."""
+    """The autoencoder's Downsample: pad (0,1,0,1) + 3x3 conv, stride 2.  f16 (whole 32-channel chunks) and
+    compensated-fp32 sections (16-channel chunks) with even sizes: the space-to-depth form on the halo-tile
+    kernel (ops.PackedDownConv, with fused GroupNorm statistics); otherwise (exact fp32 mode, ELVIS_NO_S2D=1,
+    odd sizes) the generic strided kernel - same result to rounding."""
 
     def __init__(self, sd, p, dtype, device, cin):
         import os
         self.direct = _conv(sd, p, dtype, device, cin)
         self.s2d = None
-        if dtype == torch.float16 and cin % 32 == 0 and sd[p + ".weight"].shape[0] >= 64 and not os.environ.get("ELVIS_NO_S2D"):
+        if ops.PackedDownConv.supported(dtype, cin, sd[p + ".weight"].shape[0], x3=ops._X3_DEFAULT) and not os.environ.get("ELVIS_NO_S2D"):
             self.s2d = ops.PackedDownConv(sd[p + ".weight"], sd[p + ".bias"], dtype, device, cin)
 
     def __call__(self, x: Act, want_stats=False) -> Act:

@@ -547,3 +547,46 @@ def test_swin_fused_mlp_and_ln_linear(gpu_device, c, ratio, tokens_hw):
     assert rms(got, ref_mlp) < 1.5 * rms(chain, ref_mlp) + 1e-4 and rms(gq, ref_qkv) < 1.5 * rms(qk, ref_qkv) + 1e-4
     with pytest.raises(ValueError):
         ops.SwinFused(nw[:40], nb[:40], w1[:, :40], b1, device=gpu_device)
+
+
+@pytest.mark.parametrize("cfg", [(128, 128, 20, 36), (48, 192, 18, 70), (256, 320, 34, 64)])
+def test_downsample_conv_space_to_depth_compensated(gpu_device, cfg):
+    """The same space-to-depth form on fp32 tensors with the compensated f16 MFMA (ELVIS_F32X3; the x3 / dec_f16 modes'
+    encoder): fp32-grade against the direct fp32 conv, where the exact strided kernel ran at a sixteenth of the rate."""
+    from elvis_amd import ops
+    cin, cout, h, w = cfg
+    g = torch.Generator().manual_seed(24)
+    n = 2
+    x = torch.randn(n, cin, h, w, generator=g) * 2.0
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    assert ops.PackedDownConv.supported(torch.float32, cin, cout, x3=True) and not ops.PackedDownConv.supported(torch.float32, cin, cout)
+    conv = ops.PackedDownConv(wt, b, torch.float32, gpu_device, cin)
+    y = conv(_act(x, torch.float32, gpu_device), want_stats=True)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, b, stride=2)
+    got = _nchw(y)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-4
+    assert y.stats is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("cin,cout,k,stride", [(32, 189, 3, 1), (16, 20, 3, 1), (64, 1, 3, 1), (24, 3, 1, 1), (16, 12, 3, 2)])
+def test_conv_writes_its_pad_channels(gpu_device, dtype, cin, cout, k, stride):
+    """Activations keep channels [cout, pitch) at zero (the next conv's staging reads them).  The PRODUCING conv writes
+    those zeros itself - ops no longer zero-fills every output through torch (5 % of the DCT slot) - on
+    every epilogue path: whole 4-channel groups, a ragged last group, pad-only groups, the generic strided kernel."""
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(51)
+    n, h, w = 2, 18, 34
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = ops.PackedConv(wt, b, dtype, gpu_device, cin)
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    out = ops.new_act(n, ho, wo, cout, dtype, gpu_device, zero=False)
+    out.t.fill_(float("nan"))
+    y = conv(_act(x, dtype, gpu_device), stride=stride, out=out)
+    assert y.pitch > cout or cout % 8 == 0
+    assert torch.count_nonzero(y.t[..., cout:]).item() == 0 and not torch.isnan(y.t).any()
+    ref = F.conv2d(x.to(dtype).float(), wt.to(dtype).float(), b, stride=stride, padding=k // 2)
+    assert (_nchw(y) - ref).abs().max().item() < TOL[dtype]
