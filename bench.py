@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = "profiles/r02_hbm_traffic.json"
+TRAFFIC_FILE = "profiles/r03_hbm_traffic.json"
 
 
 def parse(argv=None):

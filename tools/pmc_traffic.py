@@ -7,15 +7,24 @@ import collections, csv, json, re, sys
 
 
 def short(name: str) -> str:
+    """Kernel name as bench.py / elvis_conv_kernel_name print it, from rocprofv3's mangled or demangled form."""
     m = re.search(r"(conv3x3_halo_kernel|conv_igemm_kernel)I(DF16_|f)((?:L[ib]\d+E)+)", name)
-    if not m:
-        d = re.search(r"((?:conv3x3_halo|conv_igemm|window_attention|layernorm|vq_nearest)\w*)<([^>]*)>", name)   # demangled form
-        if d:
-            return f"{d.group(1)}<{d.group(2).replace(' ', '')}>"
-        return name.split("(")[0][:80]
-    args = re.findall(r"L([ib])(\d+)E", m.group(3))
-    vals = [("true" if v == "1" else "false") if k == "b" else v for k, v in args]
-    return f"{m.group(1)}<{'half' if m.group(2) == 'DF16_' else 'float'},{','.join(vals)}>"
+    if m:
+        args = re.findall(r"L([ib])(\d+)E", m.group(3))
+        vals = [("true" if v == "1" else "false") if k == "b" else v for k, v in args]
+        return f"{m.group(1)}<{'half' if m.group(2) == 'DF16_' else 'float'},{','.join(vals)}>"
+    m = re.search(r"\d\d([a-z]\w*?_kernel)I((?:L[ib]\d+E)+)", name)   # other mangled templates: integer / bool arguments only
+    if m:
+        args = re.findall(r"L([ib])(\d+)E", m.group(2))
+        vals = [("true" if v == "1" else "false") if k == "b" else v for k, v in args]
+        return f"{m.group(1)}<{','.join(vals)}>"
+    d = re.search(r"(\w+_kernel\w*)<([^>]*)>", name)   # demangled form
+    if d:
+        return f"{d.group(1)}<{d.group(2).replace(' ', '')}>"
+    m = re.search(r"_ZN12_GLOBAL__N_1\d+([a-z]\w*?_kernel)", name)    # mangled, non-integer template arguments
+    if m:
+        return m.group(1)
+    return name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:80]
 
 
 def collect(path, counter):
