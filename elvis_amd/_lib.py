@@ -61,6 +61,8 @@ SIGNATURES = {
     "elvis_swin_pack_weights": [vp, vp, vp, i32, i32, i32, vp],
     "elvis_swin_mlp": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp],
     "elvis_swin_ln_linear": [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp],
+    "elvis_swin_pack_proj_mlp": [vp, vp, vp, vp, i32, i32, vp],
+    "elvis_swin_proj_mlp": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp],
     "elvis_window_attention": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, vp],
     "elvis_bicubic_upsample": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "elvis_vq_nearest": [vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],

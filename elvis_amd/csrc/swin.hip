@@ -4,6 +4,10 @@
 //                                                                   tensor never leaves the CU - it was written and read
 //                                                                   back through HBM, 10 C bytes per token of 17 C)
 //   LINEAR : out = W . LayerNorm(x) + b                             (LN fused into the qkv projection)
+//   PROJ   : y' = y + Wp . a + bp ;  out = y' + fc2( GELU( fc1( LayerNorm(y') ) ) )
+//            (the attention output projection folded in front of the MLP: y' is born in the accumulator layout, LayerNorm
+//             runs on the accumulators, and stacked accumulator tiles are fc1's B operand - the same k permutation, now
+//             applied to fc1's packed columns; y' never reaches HBM: 3 C bytes per token instead of 6 C)
 //
 // A workgroup (8 waves) owns 128*PXT consecutive tokens; a wave owns 16*PXT of them and keeps their C channels in
 // registers for the whole kernel as MFMA B fragments (token = column): LayerNorm is two register passes plus two
@@ -25,7 +29,10 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 struct SwinArgs {
-    const half_t* x;      // [M, x_pitch]
+    const half_t* y;      // PROJ: the residual stream [M, y_pitch]
+    const float* bp;      // PROJ: the projection's bias [C]
+    int y_pitch;
+    const half_t* x;      // [M, x_pitch]  (PROJ: the attention output)
     half_t* out;          // [M, out_pitch]
     const half_t* w;      // packed weights: per chunk [W1 chunk | W2 chunk]
     const float* b1;      // [n1]
@@ -43,14 +50,17 @@ template <typename F> __device__ __forceinline__ F lds_frag16(const char* p) {
     return *reinterpret_cast<const F*>(__builtin_assume_aligned(p, 16));
 }
 
-template <int C, int PXT, bool MLP>
+template <int C, int PXT, int MODE>   // MODE 0: LINEAR, 1: MLP, 2: PROJ (+ MLP)
 __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
+    constexpr bool MLP = MODE >= 1, PROJ = MODE == 2;
+    constexpr int NP = PROJ ? C / 64 : 0;               // 64-row chunks of the projection in front of the MLP chunks
     constexpr int KB = C / 32;                          // 32-channel k blocks of the first GEMM
     constexpr int CT = C / 16;                          // 16-row output tiles of the second GEMM
     constexpr int W1B = KB * 4096;                      // one chunk of W1: [KB][64 rows][64 B]
     constexpr int W2B = MLP ? 2 * C * 64 : 0;           // one chunk of W2: [2 k blocks][C rows][64 B]
     constexpr int STAGE = W1B + W2B;
     constexpr int PIECES = STAGE / 16 / 512;            // LDS-DMA pieces per thread per stage
+    constexpr int PIECES1 = W1B / 16 / 512;             // ... per projection chunk (a W1-shaped block)
     static_assert(C % 64 == 0 && (STAGE / 16) % 512 == 0 && 2 * STAGE <= 160 * 1024, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -68,11 +78,14 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
         const int c = tid + i * 512;
         src_off[i] = srow_off(c >> 2, c & 3);
     }
-    auto w_issue = [&](int hc, int s) {
-        hc = hc < nchunks ? hc : nchunks - 1;           // the chunk after the last re-loads it (never read): uniform vmcnt
-        const char* base = (const char*)p.w + (long long)hc * STAGE;
+    // global chunk index g: NP projection chunks (W1-shaped blocks), then the MLP / LINEAR chunks (whole stages)
+    auto w_issue = [&](int g, int s) {
+        g = g < NP + nchunks ? g : NP + nchunks - 1;    // the chunk after the last re-loads it (never read): uniform vmcnt
+        const bool proj = g < NP;
+        const char* base = (const char*)p.w + (proj ? (long long)g * W1B : (long long)NP * W1B + (long long)(g - NP) * STAGE);
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
+            if (PROJ && proj && i >= PIECES1) break;    // (wave-uniform) a projection chunk is the W1-shaped head of a stage
             unsigned keep;
             const unsigned dst = lds_base + (unsigned)(s * STAGE + (i * 512 + wave_u * 64) * 16);
             const char* src = base + src_off[i];
@@ -82,21 +95,24 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
     };
     w_issue(0, 0);
 
-    // ---- the wave's tokens: load (B-fragment shaped), LayerNorm in registers, pack to f16
+    // ---- the wave's tokens: load (B-fragment shaped); LINEAR / MLP: LayerNorm in registers, pack to f16
     half8 xb[PXT][KB];
-    {
+#pragma unroll
+    for (int t = 0; t < PXT; ++t) {
+        const long long tok = tok0 + 16 * t + lr;
+        const half_t* src = p.x + (tok < p.M ? tok : 0) * p.x_pitch + 8 * lq;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xb[t][k] = *reinterpret_cast<const half8*>(src + 32 * k);
+    }
+    if constexpr (!PROJ) {
         float mean[PXT], rstd[PXT];
 #pragma unroll
         for (int t = 0; t < PXT; ++t) {
-            const long long tok = tok0 + 16 * t + lr;
-            const half_t* src = p.x + (tok < p.M ? tok : 0) * p.x_pitch + 8 * lq;
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                xb[t][k] = *reinterpret_cast<const half8*>(src + 32 * k);
+            for (int k = 0; k < KB; ++k)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += (float)xb[t][k][e];
-            }
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             mean[t] = s / (float)C;
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
     }
 
     float4v acc[MLP ? CT : 1][PXT];
-    if constexpr (MLP) {
+    if constexpr (MLP && !PROJ) {
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -135,12 +151,88 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
     }
     const int a_off = srow_off(lr, lq);
 
+    if constexpr (PROJ) {
+        // ---- y' = y + Wp . a + bp, chunk pc = output channels 64 pc .. 64 pc + 63 = accumulator tiles 4 pc .. 4 pc + 3
+        //      (the lane's rows of tile 4 pc + i are channels 64 pc + 16 lq + 4 i + r: the layout the epilogue stores from)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+            const int s = pc & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            w_issue(pc + 1, s ^ 1);
+            const char* w1 = smem + s * STAGE + a_off;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4v b = *reinterpret_cast<const float4v*>(p.bp + 64 * pc + 16 * lq + 4 * i);
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) acc[4 * pc + i][t] = b;
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                half8 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = lds_frag16<half8>(w1 + k * 4096 + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < PXT; ++t)
+                        acc[4 * pc + i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xb[t][k], acc[4 * pc + i][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) {
+                const long long tok = tok0 + 16 * t + lr;
+                const half_t* yp = p.y + (tok < p.M ? tok : 0) * p.y_pitch + 64 * pc + 16 * lq;
+                const half8 r0 = *reinterpret_cast<const half8*>(yp), r1 = *reinterpret_cast<const half8*>(yp + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[4 * pc + i][t][r] += (float)(i < 2 ? r0[4 * i + r] : r1[4 * (i - 2) + r]);
+            }
+        }
+        // ---- LayerNorm of y' on the accumulators (a token's C values: CT x 4 in this lane, the rest in the lanes 16 / 32
+        //      / 48 away), written as fc1's B fragments: element j of k block m is tile 2 m + (j >> 2), row 4 lq + (j & 3)
+        //      = channel 64 (m >> 1) + 16 lq + 8 (m & 1) + j - fc1's columns are packed in that order
+#pragma unroll
+        for (int t = 0; t < PXT; ++t) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += acc[c][t][r];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[c][t][r] - mean;
+                    q = fmaf(d, d, q);
+                }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = 1.0f / sqrtf(q / (float)C + p.eps);
+#pragma unroll
+            for (int m = 0; m < KB; ++m) {
+                const int ch = 64 * (m >> 1) + 16 * lq + 8 * (m & 1);
+                const float4v g0 = *reinterpret_cast<const float4v*>(p.gamma + ch), g1 = *reinterpret_cast<const float4v*>(p.gamma + ch + 4);
+                const float4v h0 = *reinterpret_cast<const float4v*>(p.beta + ch), h1 = *reinterpret_cast<const float4v*>(p.beta + ch + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = j < 4 ? g0[j & 3] : g1[j & 3], h = j < 4 ? h0[j & 3] : h1[j & 3];
+                    xb[t][m][j] = (half_t)((acc[2 * m + (j >> 2)][t][j & 3] - mean) * rstd * g + h);
+                }
+            }
+        }
+    }
+
     for (int hc = 0; hc < nchunks; ++hc) {
-        const int s = hc & 1;
+        const int s = (NP + hc) & 1;
         // chunk hc has landed (this thread's pieces: the only DMAs in flight), and everyone is past chunk hc-1's reads
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        w_issue(hc + 1, s ^ 1);
+        w_issue(NP + hc + 1, s ^ 1);
         const char* w1 = smem + s * STAGE + a_off;
         float4v S[4][PXT];
         // bias of this chunk's 64 rows: lane's rows are 16 i + 4 lq + r (MLP) or channels 16 lq + 4 i + r (LINEAR)
@@ -208,14 +300,18 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
 #pragma unroll
             for (int g = 0; g < C / 64; ++g) {
                 const int ch = 64 * g + 16 * lq;
-                const half8 r0 = *reinterpret_cast<const half8*>(p.x + tc * p.x_pitch + ch), r1 = *reinterpret_cast<const half8*>(p.x + tc * p.x_pitch + ch + 8);
+                half8 r0 = {}, r1 = {};   // (PROJ: the accumulators started from y + proj: nothing to add)
+                if constexpr (!PROJ) {
+                    r0 = *reinterpret_cast<const half8*>(p.x + tc * p.x_pitch + ch);
+                    r1 = *reinterpret_cast<const half8*>(p.x + tc * p.x_pitch + ch + 8);
+                }
                 half8 lo, hi;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float4v b = *reinterpret_cast<const float4v*>(p.b2 + ch + 4 * i);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float res = (float)(i < 2 ? r0[4 * i + r] : r1[4 * (i - 2) + r]);
+                        const float res = PROJ ? 0.f : (float)(i < 2 ? r0[4 * i + r] : r1[4 * (i - 2) + r]);
                         const half_t v = (half_t)(acc[4 * g + i][t][r] + b[r] + res);
                         if (i < 2) lo[4 * i + r] = v; else hi[4 * (i - 2) + r] = v;
                     }
@@ -230,8 +326,8 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
     }
 }
 
-template <int C, int PXT, bool MLP> int launch_swin(const SwinArgs& a, hipStream_t stream) {
-    constexpr int STAGE = (C / 32) * 4096 + (MLP ? 2 * C * 64 : 0);
+template <int C, int PXT, int MODE> int launch_swin(const SwinArgs& a, hipStream_t stream) {
+    constexpr int STAGE = (C / 32) * 4096 + (MODE >= 1 ? 2 * C * 64 : 0);
     const size_t lds = 2 * (size_t)STAGE;
     {
         static std::mutex mu;
@@ -240,7 +336,7 @@ template <int C, int PXT, bool MLP> int launch_swin(const SwinArgs& a, hipStream
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         std::lock_guard<std::mutex> guard(mu);
         if (!attr_set[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)swin_fused_kernel<C, PXT, MLP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)swin_fused_kernel<C, PXT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) {
                 elvis_set_error("elvis_swin: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
                 return ELVIS_E_RUNTIME;
@@ -251,17 +347,17 @@ template <int C, int PXT, bool MLP> int launch_swin(const SwinArgs& a, hipStream
     const long long per = 128LL * PXT;
     const long long blocks = (a.M + per - 1) / per;
     ELVIS_REQUIRE(blocks < 0x7fffffffLL, "elvis_swin: grid too large");
-    hipLaunchKernelGGL((swin_fused_kernel<C, PXT, MLP>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((swin_fused_kernel<C, PXT, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_swin");
     return ELVIS_OK;
 }
 
-template <bool MLP> int dispatch_swin(int c, const SwinArgs& a, hipStream_t stream) {
+template <int MODE> int dispatch_swin(int c, const SwinArgs& a, hipStream_t stream) {
     switch (c) {
-        case 64: return launch_swin<64, 2, MLP>(a, stream);
-        case 128: return launch_swin<128, 2, MLP>(a, stream);
-        case 192: return launch_swin<192, 2, MLP>(a, stream);
-        case 256: return launch_swin<256, 1, MLP>(a, stream);    // 128 accumulator registers at two tokens tiles: one
+        case 64: return launch_swin<64, 2, MODE>(a, stream);
+        case 128: return launch_swin<128, 2, MODE>(a, stream);
+        case 192: return launch_swin<192, 2, MODE>(a, stream);
+        case 256: return launch_swin<256, 1, MODE>(a, stream);    // 128 accumulator registers at two tokens tiles: one
         default: break;
     }
     elvis_set_error("elvis_swin: channels must be 64, 128, 192 or 256 (got %d)", c);
@@ -279,34 +375,52 @@ static int check_common(const void* x, const void* out, const void* w, const flo
 
 }  // namespace
 
-extern "C" size_t elvis_swin_packed_bytes(int c, int n1, int mlp) {
-    if (c <= 0 || c % 64 || n1 <= 0 || n1 % 64) return 0;
-    return (size_t)(n1 / 64) * ((size_t)(c / 32) * 4096 + (mlp ? 2 * (size_t)c * 64 : 0));
+extern "C" size_t elvis_swin_packed_bytes(int c, int n1, int mode) {
+    if (c <= 0 || c % 64 || n1 <= 0 || n1 % 64 || mode < 0 || mode > 2) return 0;
+    const size_t w1b = (size_t)(c / 32) * 4096;
+    return (mode == 2 ? (size_t)(c / 64) * w1b : 0) + (size_t)(n1 / 64) * (w1b + (mode ? 2 * (size_t)c * 64 : 0));
 }
 
 // OIHW-style fp32 weights -> the kernels' packed f16 stream: per 64-row chunk hc of the first matrix
 //   [k block][64 rows][32 halfs] of W1 (rows in natural order for the MLP, in the 16-contiguous-channels-per-lane order
 //   for LINEAR), then for the MLP [2 k blocks][C rows][32 halfs] of W2's columns 64 hc .. 64 hc + 63 (rows in the
 //   16-contiguous order, columns in the accumulator-as-operand order, swin_fused_kernel).
-__global__ void swin_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, half_t* __restrict__ out, int c, int n1,
-                                 int mlp, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void swin_pack_kernel(const float* __restrict__ wp, const float* __restrict__ w1, const float* __restrict__ w2,
+                                 half_t* __restrict__ out, int c, int n1, int mode, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    const long long i0 = i;
     const int kb_n = c / 32;
-    const long long stage = (long long)kb_n * 2048 + (mlp ? 2LL * c * 32 : 0);    // halfs per chunk
+    const long long w1h = (long long)kb_n * 2048;                                 // halfs of one W1-shaped block
+    if (mode == 2) {                                                              // the projection's chunks come first
+        const long long ph = (long long)(c / 64) * w1h;
+        if (i < ph) {
+            const int pc = (int)(i / w1h);
+            const long long r = i - (long long)pc * w1h;
+            const int kk = (int)(r & 31), row = (int)((r >> 5) & 63), kb = (int)(r >> 11);
+            const int i4 = row >> 4, q = (row >> 2) & 3, rr = row & 3;
+            out[i0] = (half_t)wp[(long long)(64 * pc + 16 * q + 4 * i4 + rr) * c + 32 * kb + kk];
+            return;
+        }
+        i -= ph;
+    }
+    const long long stage = w1h + (mode ? 2LL * c * 32 : 0);                      // halfs per chunk
     const int hc = (int)(i / stage);
     long long r = i - (long long)hc * stage;
     float v;
-    if (r < (long long)kb_n * 2048) {
+    if (r < w1h) {
         const int kk = (int)(r & 31), row = (int)((r >> 5) & 63), kb = (int)(r >> 11);
         int o = 64 * hc + row;                                        // MLP: hidden row, natural order
-        if (!mlp) {
+        if (mode == 0) {
             const int i4 = row >> 4, q = (row >> 2) & 3, rr = row & 3;
             o = 64 * hc + 16 * q + 4 * i4 + rr;
         }
-        v = w1[(long long)o * c + 32 * kb + kk];
+        int col = 32 * kb + kk;
+        if (mode == 2)                                                // fc1 reads LayerNorm(y') out of the accumulator tiles
+            col = 64 * (kb >> 1) + 16 * (kk >> 3) + 8 * (kb & 1) + (kk & 7);
+        v = w1[(long long)o * c + col];
     } else {
-        r -= (long long)kb_n * 2048;
+        r -= w1h;
         const int kk = (int)(r & 31);
         const int row = (int)((r >> 5) % c), m = (int)((r >> 5) / c);
         const int g = row >> 6, i4 = (row >> 4) & 3, q = (row >> 2) & 3, rr = row & 3;
@@ -315,18 +429,28 @@ __global__ void swin_pack_kernel(const float* __restrict__ w1, const float* __re
         const int hid = 64 * hc + 32 * m + 16 * (j >> 2) + 4 * lqk + (j & 3);
         v = w2[(long long)co * n1 + hid];
     }
-    out[i] = (half_t)v;
+    out[i0] = (half_t)v;
+}
+
+static int pack_common(const float* wp, const float* w1, const float* w2, void* packed, int c, int n1, int mode, hipStream_t stream) {
+    const size_t bytes = elvis_swin_packed_bytes(c, n1, mode);
+    ELVIS_REQUIRE(bytes > 0, "elvis_swin_pack_weights: c (%d) and n1 (%d) must be positive multiples of 64", c, n1);
+    const long long total = (long long)(bytes / 2);
+    hipLaunchKernelGGL(swin_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wp, w1, w2, (half_t*)packed, c, n1,
+                       mode, total);
+    ELVIS_CHECK_LAUNCH("elvis_swin_pack_weights");
+    return ELVIS_OK;
 }
 
 extern "C" int elvis_swin_pack_weights(const float* w1, const float* w2, void* packed, int c, int n1, int mlp, elvis_stream_t stream) {
     ELVIS_REQUIRE(w1 && packed && (!mlp || w2), "elvis_swin_pack_weights: null pointer");
-    const size_t bytes = elvis_swin_packed_bytes(c, n1, mlp);
-    ELVIS_REQUIRE(bytes > 0, "elvis_swin_pack_weights: c (%d) and n1 (%d) must be positive multiples of 64", c, n1);
-    const long long total = (long long)(bytes / 2);
-    hipLaunchKernelGGL(swin_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, w2, (half_t*)packed, c, n1,
-                       mlp, total);
-    ELVIS_CHECK_LAUNCH("elvis_swin_pack_weights");
-    return ELVIS_OK;
+    return pack_common(nullptr, w1, w2, packed, c, n1, mlp ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int elvis_swin_pack_proj_mlp(const float* wp, const float* w1, const float* w2, void* packed, int c, int hidden,
+                                        elvis_stream_t stream) {
+    ELVIS_REQUIRE(wp && w1 && w2 && packed, "elvis_swin_pack_proj_mlp: null pointer");
+    return pack_common(wp, w1, w2, packed, c, hidden, 2, (hipStream_t)stream);
 }
 
 extern "C" int elvis_swin_mlp(const void* x, void* out, const void* packed, const float* b1, const float* b2, const float* gamma,
@@ -336,8 +460,8 @@ extern "C" int elvis_swin_mlp(const void* x, void* out, const void* packed, cons
     if (rc) return rc;
     ELVIS_REQUIRE(b1 && b2 && hidden > 0 && hidden % 64 == 0, "elvis_swin_mlp: hidden (%d) must be a positive multiple of 64", hidden);
     ELVIS_REQUIRE((((uintptr_t)b1 | (uintptr_t)b2) & 15) == 0, "elvis_swin_mlp: biases must be 16-byte aligned");
-    SwinArgs a{(const half_t*)x, (half_t*)out, (const half_t*)packed, b1, b2, gamma, beta, tokens, x_pitch, out_pitch, hidden, eps};
-    return dispatch_swin<true>(c, a, (hipStream_t)stream);
+    SwinArgs a{nullptr, nullptr, 0, (const half_t*)x, (half_t*)out, (const half_t*)packed, b1, b2, gamma, beta, tokens, x_pitch, out_pitch, hidden, eps};
+    return dispatch_swin<1>(c, a, (hipStream_t)stream);
 }
 
 extern "C" int elvis_swin_ln_linear(const void* x, void* out, const void* packed, const float* bias, const float* gamma, const float* beta,
@@ -345,6 +469,19 @@ extern "C" int elvis_swin_ln_linear(const void* x, void* out, const void* packed
     int rc = check_common(x, out, packed, gamma, beta, tokens, c, x_pitch, out_pitch, n_out);
     if (rc) return rc;
     ELVIS_REQUIRE(bias && n_out > 0 && n_out % 64 == 0 && (((uintptr_t)bias) & 15) == 0, "elvis_swin_ln_linear: n_out (%d) must be a positive multiple of 64, bias 16-byte aligned", n_out);
-    SwinArgs a{(const half_t*)x, (half_t*)out, (const half_t*)packed, bias, nullptr, gamma, beta, tokens, x_pitch, out_pitch, n_out, eps};
-    return dispatch_swin<false>(c, a, (hipStream_t)stream);
+    SwinArgs a{nullptr, nullptr, 0, (const half_t*)x, (half_t*)out, (const half_t*)packed, bias, nullptr, gamma, beta, tokens, x_pitch, out_pitch, n_out, eps};
+    return dispatch_swin<0>(c, a, (hipStream_t)stream);
+}
+
+extern "C" int elvis_swin_proj_mlp(const void* attn, const void* y, void* out, const void* packed, const float* bp, const float* b1,
+                                   const float* b2, const float* gamma, const float* beta, long long tokens, int c, int hidden,
+                                   int attn_pitch, int y_pitch, int out_pitch, float eps, elvis_stream_t stream) {
+    int rc = check_common(attn, out, packed, gamma, beta, tokens, c, attn_pitch, out_pitch, c);
+    if (rc) return rc;
+    ELVIS_REQUIRE(y && bp && b1 && b2 && hidden > 0 && hidden % 64 == 0 && y_pitch >= c && y_pitch % 8 == 0,
+                  "elvis_swin_proj_mlp: hidden (%d) must be a positive multiple of 64, y_pitch (%d) >= c and a multiple of 8", hidden, y_pitch);
+    ELVIS_REQUIRE((((uintptr_t)y | (uintptr_t)bp | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0, "elvis_swin_proj_mlp: pointers must be 16-byte aligned");
+    SwinArgs a{(const half_t*)y, bp, y_pitch, (const half_t*)attn, (half_t*)out, (const half_t*)packed, b1, b2, gamma, beta, tokens, attn_pitch,
+               out_pitch, hidden, eps};
+    return dispatch_swin<2>(c, a, (hipStream_t)stream);
 }

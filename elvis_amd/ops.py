@@ -504,6 +504,8 @@ class SwinFused:
 
       SwinFused(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b)  ->  __call__(x) = x + fc2(GELU(fc1(LN(x))))   (the Swin MLP)
       SwinFused(norm_w, norm_b, w, b)                        ->  __call__(x) = w . LN(x) + b               (LN + qkv)
+      SwinFused(..., fc2_w, fc2_b, proj_w=, proj_b=)         ->  __call__(a, y): y' = y + proj(a); y' + fc2(GELU(fc1(LN(y'))))
+                                                                 (the attention output projection folded in front of the MLP)
 
     `supported(c, n1)` says whether a shape has a fused kernel (channels 64 / 128 / 192 / 256, outputs a multiple of 64);
     callers keep the separate layernorm + 1x1-conv kernels for everything else (fp32 / compensated modes too)."""
@@ -512,28 +514,52 @@ class SwinFused:
     def supported(dtype, c: int, n1: int) -> bool:
         return dtype == torch.float16 and c in SWIN_FUSED_CHANNELS and n1 % 64 == 0
 
-    def __init__(self, norm_w, norm_b, w1, b1, w2=None, b2=None, *, device, eps: float = 1e-5):
+    @staticmethod
+    def proj_pays(c: int) -> bool:
+        """Folding the projection in front of the MLP pays where the MLP kernel has registers to spare: at C = 192 with
+        two token tiles per wave the combined kernel sits at 256 VGPRs (84 spilled around its LayerNorm) and takes as
+        long as the separate projection + MLP kernels (988 vs 769 + 195 us per launch, SinSR); at 64 / 128 / 256 it is
+        9 % of the Blur slot."""
+        return c != 192
+
+    def __init__(self, norm_w, norm_b, w1, b1, w2=None, b2=None, *, proj_w=None, proj_b=None, device, eps: float = 1e-5):
         n1, c = w1.shape[0], w1.shape[1]
         if not self.supported(torch.float16, c, n1):
             raise ValueError(f"no fused Swin kernel for {c} channels / {n1} outputs")
         self.c, self.n1, self.mlp, self.eps, self.device = c, n1, w2 is not None, float(eps), device
+        self.proj = proj_w is not None
+        if self.proj and not self.mlp:
+            raise ValueError("the projection is fused in front of an MLP only")
+        self.mode = 2 if self.proj else int(self.mlp)
         f32 = dict(device=device, dtype=torch.float32)
         w1d = w1.reshape(n1, c).to(**f32).contiguous()
         w2d = w2.reshape(c, n1).to(**f32).contiguous() if self.mlp else None
-        self.packed = torch.empty(lib().elvis_swin_packed_bytes(c, n1, int(self.mlp)), dtype=torch.uint8, device=device)
-        check(lib().elvis_swin_pack_weights(ptr(w1d), ptr(w2d), ptr(self.packed), c, n1, int(self.mlp), _s(self.packed)), device)
-        torch.cuda.current_stream(device).synchronize()   # w1d / w2d may be freed after return
+        self.packed = torch.empty(lib().elvis_swin_packed_bytes(c, n1, self.mode), dtype=torch.uint8, device=device)
+        if self.proj:
+            wpd = proj_w.reshape(c, c).to(**f32).contiguous()
+            check(lib().elvis_swin_pack_proj_mlp(ptr(wpd), ptr(w1d), ptr(w2d), ptr(self.packed), c, n1, _s(self.packed)), device)
+            self.bp = proj_b.to(**f32).contiguous()
+        else:
+            check(lib().elvis_swin_pack_weights(ptr(w1d), ptr(w2d), ptr(self.packed), c, n1, int(self.mlp), _s(self.packed)), device)
+        torch.cuda.current_stream(device).synchronize()   # the fp32 copies may be freed after return
         self.b1 = b1.to(**f32).contiguous()
         self.b2 = b2.to(**f32).contiguous() if self.mlp else None
         self.gamma, self.beta = norm_w.to(**f32).contiguous(), norm_b.to(**f32).contiguous()
 
-    def __call__(self, x: Act) -> Act:
+    def __call__(self, x: Act, y: Optional[Act] = None) -> Act:
         if x.c != self.c or x.t.dtype != torch.float16:
             raise ValueError(f"fused Swin block: expected f16 with {self.c} channels, got {x.t.dtype} with {x.c}")
+        if self.proj != (y is not None) or (y is not None and (y.c != self.c or y.t.dtype != torch.float16 or y.t.shape[:3] != x.t.shape[:3])):
+            raise ValueError("fused Swin block: the projection form takes (attention output, residual stream) of one shape")
         tokens = x.n * x.h * x.w
         cout = self.c if self.mlp else self.n1
         out = new_act(x.n, x.h, x.w, cout, torch.float16, x.t.device, zero=False)
-        if self.mlp:
+        if self.proj:
+            with _Timed("swin_proj_mlp", "mfma", (4.0 * self.c * self.n1 + 2.0 * self.c * self.c) * tokens):
+                check(lib().elvis_swin_proj_mlp(ptr(x.t), ptr(y.t), ptr(out.t), ptr(self.packed), ptr(self.bp), ptr(self.b1), ptr(self.b2),
+                                                ptr(self.gamma), ptr(self.beta), tokens, self.c, self.n1, x.pitch, y.pitch, out.pitch,
+                                                self.eps, _s(x.t)), x.t.device)
+        elif self.mlp:
             with _Timed("swin_mlp", "mfma", 4.0 * self.c * self.n1 * tokens):
                 check(lib().elvis_swin_mlp(ptr(x.t), ptr(out.t), ptr(self.packed), ptr(self.b1), ptr(self.b2), ptr(self.gamma),
                                            ptr(self.beta), tokens, self.c, self.n1, x.pitch, out.pitch, self.eps, _s(x.t)), x.t.device)

@@ -133,8 +133,10 @@ class _SwinLayer:
             self.blocks.append(dict(
                 # f16: LayerNorm + qkv in one kernel, LayerNorm + fc1 + GELU + fc2 + residual in one kernel (csrc/swin.hip)
                 qkv_f=ops.SwinFused(w(".norm1.weight"), w(".norm1.bias"), w(".attn.qkv.weight"), w(".attn.qkv.bias"), device=device) if fuse else None,
+                # ... and the attention output projection folded in front of the MLP: y' = y + proj(a) never reaches HBM
                 mlp_f=ops.SwinFused(w(".norm2.weight"), w(".norm2.bias"), w(".mlp.fc1.weight"), w(".mlp.fc1.bias"),
-                                    w(".mlp.fc2.weight"), w(".mlp.fc2.bias"), device=device) if fuse else None,
+                                    w(".mlp.fc2.weight"), w(".mlp.fc2.bias"), device=device,
+                                    **(dict(proj_w=w(".attn.proj.weight"), proj_b=w(".attn.proj.bias")) if ops.SwinFused.proj_pays(E) else {})) if fuse else None,
                 n1=(sd[b + ".norm1.weight"].to(**f32), sd[b + ".norm1.bias"].to(**f32)),
                 n2=(sd[b + ".norm2.weight"].to(**f32), sd[b + ".norm2.bias"].to(**f32)),
                 qkv=_linear(sd, b + ".attn.qkv", dtype, device),
@@ -154,10 +156,10 @@ class _SwinLayer:
             a = ops.window_attention(qkv, cfg.heads, cfg.num_head_channels, cfg.window_size, b["shift"], b["table"],
                                      cfg.num_head_channels ** -0.5)
             del qkv
-            y = b["proj"](a, residual=y)
             if b["mlp_f"] is not None:
-                y = b["mlp_f"](y)
+                y = b["mlp_f"](a, y) if b["mlp_f"].proj else b["mlp_f"](b["proj"](a, residual=y))
             else:
+                y = b["proj"](a, residual=y)
                 t = ops.layernorm(y, *b["n2"])
                 t = b["fc1"](t, act=1)
                 y = b["fc2"](t, residual=y)

@@ -224,13 +224,20 @@ int elvis_layernorm(const void* x, void* y, int dtype, long long tokens, int c, 
  * biases, gamma, beta f32; all pointers 16-byte aligned.  Weights are packed once by elvis_swin_pack_weights from
  * row-major f32 matrices w1[n1, c] (fc1 or the projection) and, for the MLP, w2[c, n1] (fc2) into
  * elvis_swin_packed_bytes(c, n1, mlp) bytes. */
-size_t elvis_swin_packed_bytes(int c, int n1, int mlp);
+size_t elvis_swin_packed_bytes(int c, int n1, int mode);   /* mode 0: LN + linear, 1: MLP, 2: projection + MLP */
 int elvis_swin_pack_weights(const float* w1, const float* w2, void* packed, int c, int n1, int mlp, elvis_stream_t stream);
 int elvis_swin_mlp(const void* x, void* out, const void* packed, const float* b1, const float* b2, const float* gamma,
                    const float* beta, long long tokens, int c, int hidden, int x_pitch, int out_pitch, float eps,
                    elvis_stream_t stream);
 int elvis_swin_ln_linear(const void* x, void* out, const void* packed, const float* bias, const float* gamma, const float* beta,
                          long long tokens, int c, int n_out, int x_pitch, int out_pitch, float eps, elvis_stream_t stream);
+/*   elvis_swin_proj_mlp  : y' = y + Wp . attn + bp ; out = y' + fc2(GELU(fc1(LayerNorm(y'))))  - the attention output projection
+ *                          folded in front of the MLP (y' never reaches HBM).  Weights packed by elvis_swin_pack_proj_mlp from
+ *                          wp[c, c], w1[hidden, c], w2[c, hidden] into elvis_swin_packed_bytes(c, hidden, 2) bytes. */
+int elvis_swin_pack_proj_mlp(const float* wp, const float* w1, const float* w2, void* packed, int c, int hidden, elvis_stream_t stream);
+int elvis_swin_proj_mlp(const void* attn, const void* y, void* out, const void* packed, const float* bp, const float* b1,
+                        const float* b2, const float* gamma, const float* beta, long long tokens, int c, int hidden,
+                        int attn_pitch, int y_pitch, int out_pitch, float eps, elvis_stream_t stream);
 
 /* Swin (shifted-)window attention on a token image qkv[n,h,w,3*E] (q|k|v, head-major inside
  * each), window ws, `shift` cyclic shift (0 or ws/2) with the standard region mask, relative

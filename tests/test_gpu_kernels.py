@@ -547,6 +547,22 @@ def test_swin_fused_mlp_and_ln_linear(gpu_device, c, ratio, tokens_hw):
     assert rms(got, ref_mlp) < 1.5 * rms(chain, ref_mlp) + 1e-4 and rms(gq, ref_qkv) < 1.5 * rms(qk, ref_qkv) + 1e-4
     with pytest.raises(ValueError):
         ops.SwinFused(nw[:40], nb[:40], w1[:, :40], b1, device=gpu_device)
+    # the projection folded in front of the MLP: y' = y + proj(a); out = y' + fc2(GELU(fc1(LN(y'))))
+    a = torch.randn(n, c, h, w, generator=g)
+    wp, bp = torch.randn(c, c, generator=g) / math.sqrt(c), torch.randn(c, generator=g) * 0.1
+    aa = _act(a, torch.float16, gpu_device)
+    y1 = xt + F.linear(q(a).permute(0, 2, 3, 1), q(wp), bp)              # kept in fp32 by the fused kernel
+    ln1 = q(F.layer_norm(y1, (c,), nw, nb, 1e-5))
+    ref_pm = y1 + F.linear(q(F.gelu(F.linear(ln1, q(w1), b1))), q(w2), b2)
+    pm = ops.SwinFused(nw, nb, w1, b1, w2, b2, proj_w=wp, proj_b=bp, device=gpu_device)
+    got_pm = pm(aa, xa).t[..., :c].float().cpu()
+    assert (got_pm - ref_pm).abs().max().item() < 2e-2
+    proj = ops.PackedConv(wp[:, :, None, None], bp, torch.float16, gpu_device, c)
+    chain_pm = mlp(proj(aa, residual=xa)).t[..., :c].float().cpu()        # unfused projection + the fused MLP
+    assert (got_pm - chain_pm).abs().max().item() < 2e-2
+    assert rms(got_pm, ref_pm) < 1.5 * rms(chain_pm, ref_pm) + 1e-4
+    with pytest.raises(ValueError):
+        pm(aa)                                                            # the projection form needs the residual stream
 
 
 @pytest.mark.parametrize("cfg", [(128, 128, 20, 36), (48, 192, 18, 70), (256, 320, 34, 64)])
