@@ -19,10 +19,11 @@
 // second GEMM accumulates out[C x 16*PXT] over all hidden chunks in registers; the epilogue adds bias and the residual
 // and stores.  Output rows are permuted at packing time (as in the conv kernels) so that a lane owns 16 contiguous
 // channels of a token: 16-byte stores and residual loads.
-// Matrix work per MFMA-LDS byte is low here (a weight fragment feeds PXT MFMAs), so the kernel is paced by the GELU's
-// VALU and the weight stream, not by HBM: ~55 % matrix-pipe busy at C = 192 against the unfused chain's HBM-bound ~10 %.
+// The MLP is paced by the GELU's VALU (16 instructions per hidden value) rather than by its MFMAs or by HBM; waves 4-7 run
+// half a chunk behind waves 0-3 so that one SIMD partner's GELU overlaps the other's matrix part.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -50,7 +51,7 @@ template <typename F> __device__ __forceinline__ F lds_frag16(const char* p) {
     return *reinterpret_cast<const F*>(__builtin_assume_aligned(p, 16));
 }
 
-template <int C, int PXT, int MODE>   // MODE 0: LINEAR, 1: MLP, 2: PROJ (+ MLP)
+template <int C, int PXT, int MODE, bool STAG>   // MODE 0: LINEAR, 1: MLP, 2: PROJ (+ MLP); STAG: waves 4-7 half a chunk behind
 __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
     constexpr bool MLP = MODE >= 1, PROJ = MODE == 2;
     constexpr int NP = PROJ ? C / 64 : 0;               // 64-row chunks of the projection in front of the MLP chunks
@@ -227,34 +228,31 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
         }
     }
 
-    for (int hc = 0; hc < nchunks; ++hc) {
-        const int s = (NP + hc) & 1;
-        // chunk hc has landed (this thread's pieces: the only DMAs in flight), and everyone is past chunk hc-1's reads
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        w_issue(NP + hc + 1, s ^ 1);
-        const char* w1 = smem + s * STAGE + a_off;
-        float4v S[4][PXT];
-        // bias of this chunk's 64 rows: lane's rows are 16 i + 4 lq + r (MLP) or channels 16 lq + 4 i + r (LINEAR)
+    if constexpr (MLP && !STAG) {
+        // ---- the MLP loop, all eight waves in lockstep: one barrier per chunk
+        for (int hc = 0; hc < nchunks; ++hc) {
+            const int s = (NP + hc) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            w_issue(NP + hc + 1, s ^ 1);
+            const char* w1 = smem + s * STAGE + a_off;
+            float4v S[4][PXT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4v b = *reinterpret_cast<const float4v*>(p.b1 + 64 * hc + (MLP ? 16 * i + 4 * lq : 16 * lq + 4 * i));
+            for (int i = 0; i < 4; ++i) {
+                const float4v b = *reinterpret_cast<const float4v*>(p.b1 + 64 * hc + 16 * i + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < PXT; ++t) S[i][t] = b;
-        }
+                for (int t = 0; t < PXT; ++t) S[i][t] = b;
+            }
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            half8 a[4];
+            for (int k = 0; k < KB; ++k) {
+                half8 a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = lds_frag16<half8>(w1 + k * 4096 + i * 1024);
+                for (int i = 0; i < 4; ++i) a[i] = lds_frag16<half8>(w1 + k * 4096 + i * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int t = 0; t < PXT; ++t) S[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xb[t][k], S[i][t], 0, 0, 0);
-        }
-        if constexpr (MLP) {
-            // GELU, then two stacked 16-row tiles are one 32-deep B fragment: element j of lane (token, q) is hidden row
-            // 32 m + 16 (j >> 2) + 4 q + (j & 3) of the chunk - fc2's columns are packed in that order
+                    for (int t = 0; t < PXT; ++t) S[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xb[t][k], S[i][t], 0, 0, 0);
+            }
             half8 H[PXT][2];
 #pragma unroll
             for (int t = 0; t < PXT; ++t)
@@ -271,8 +269,94 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
 #pragma unroll
                     for (int t = 0; t < PXT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, H[t][m], acc[c][t], 0, 0, 0);
                 }
-        } else {
-            // LINEAR: the chunk's 64 output channels of each token: the lane's 16 contiguous ones as two 16-byte stores
+        }
+    } else if constexpr (MLP) {
+        // ---- the MLP loop, STAGGERED: a chunk is two half-steps separated by workgroup barriers,
+        //        X(c) = fc1 chunk c (48 MFMAs) + GELU of its first 32 rows,   Y(c) = GELU of the other 32 rows + fc2 chunk c (48 MFMAs),
+        //      and waves 4-7 run one half-step behind waves 0-3.  Waves w and w + 4 share a SIMD, so while one of them is in
+        //      its matrix part the other is in its GELU part: the GELU's VALU (longer than the MFMAs) no longer serializes
+        //      with them as it does when all eight waves run in lockstep (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+        //      Chunk c sits in stage (NP + c) & 1 during half-steps 2c .. 2c+2; its successor in that stage, chunk c + 2, is
+        //      requested at half-step 2c + 3 and waited for (vmcnt(0) + barrier) at 2c + 4.
+        const int grp = wave >> 2;
+        float4v S[4][PXT];
+        half8 H[PXT][2];
+        for (int tau = 0; tau <= 2 * nchunks; ++tau) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tau & 1) {
+                const int c = (tau + 1) >> 1;
+                if (c < nchunks) w_issue(NP + c, (NP + c) & 1);
+            }
+            const int u = tau - grp;                       // this wave's own half-step
+            if (u < 0 || u >= 2 * nchunks) continue;
+            const int hc = u >> 1, s = (NP + hc) & 1;
+            if ((u & 1) == 0) {
+                const char* w1 = smem + s * STAGE + a_off;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {               // bias: the lane's rows of tile i are 16 i + 4 lq + r
+                    const float4v b = *reinterpret_cast<const float4v*>(p.b1 + 64 * hc + 16 * i + 4 * lq);
+#pragma unroll
+                    for (int t = 0; t < PXT; ++t) S[i][t] = b;
+                }
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    half8 a[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = lds_frag16<half8>(w1 + k * 4096 + i * 1024);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int t = 0; t < PXT; ++t) S[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xb[t][k], S[i][t], 0, 0, 0);
+                }
+                // GELU; two stacked 16-row tiles are one 32-deep B fragment: element j of lane (token, q) is hidden row
+                // 32 m + 16 (j >> 2) + 4 q + (j & 3) of the chunk - fc2's columns are packed in that order
+#pragma unroll
+                for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) H[t][0][j] = (half_t)gelu_erf_f(S[j >> 2][t][j & 3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) H[t][1][j] = (half_t)gelu_erf_f(S[2 + (j >> 2)][t][j & 3]);
+                const char* w2 = smem + s * STAGE + W1B + a_off;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const half8 a = lds_frag16<half8>(w2 + m * (C * 64) + c * 1024);
+#pragma unroll
+                        for (int t = 0; t < PXT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, H[t][m], acc[c][t], 0, 0, 0);
+                    }
+            }
+        }
+    } else {
+        for (int hc = 0; hc < nchunks; ++hc) {
+            const int s = hc & 1;
+            // chunk hc has landed (this thread's pieces: the only DMAs in flight), and everyone is past chunk hc-1's reads
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            w_issue(hc + 1, s ^ 1);
+            const char* w1 = smem + s * STAGE + a_off;
+            float4v S[4][PXT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                   // bias: the lane's channels of tile i are 16 lq + 4 i + r
+                const float4v b = *reinterpret_cast<const float4v*>(p.b1 + 64 * hc + 16 * lq + 4 * i);
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) S[i][t] = b;
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                half8 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = lds_frag16<half8>(w1 + k * 4096 + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < PXT; ++t) S[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xb[t][k], S[i][t], 0, 0, 0);
+            }
+            // the chunk's 64 output channels of each token: the lane's 16 contiguous ones as two 16-byte stores
 #pragma unroll
             for (int t = 0; t < PXT; ++t) {
                 const long long tok = tok0 + 16 * t + lr;
@@ -326,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void swin_fused_kernel(SwinArgs p) {
     }
 }
 
-template <int C, int PXT, int MODE> int launch_swin(const SwinArgs& a, hipStream_t stream) {
+template <int C, int PXT, int MODE, bool STAG> int launch_swin(const SwinArgs& a, hipStream_t stream) {
     constexpr int STAGE = (C / 32) * 4096 + (MODE >= 1 ? 2 * C * 64 : 0);
     const size_t lds = 2 * (size_t)STAGE;
     {
@@ -336,7 +420,7 @@ template <int C, int PXT, int MODE> int launch_swin(const SwinArgs& a, hipStream
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         std::lock_guard<std::mutex> guard(mu);
         if (!attr_set[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)swin_fused_kernel<C, PXT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)swin_fused_kernel<C, PXT, MODE, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) {
                 elvis_set_error("elvis_swin: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
                 return ELVIS_E_RUNTIME;
@@ -347,17 +431,32 @@ template <int C, int PXT, int MODE> int launch_swin(const SwinArgs& a, hipStream
     const long long per = 128LL * PXT;
     const long long blocks = (a.M + per - 1) / per;
     ELVIS_REQUIRE(blocks < 0x7fffffffLL, "elvis_swin: grid too large");
-    hipLaunchKernelGGL((swin_fused_kernel<C, PXT, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((swin_fused_kernel<C, PXT, MODE, STAG>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     ELVIS_CHECK_LAUNCH("elvis_swin");
     return ELVIS_OK;
 }
 
+// Stagger (waves 4-7 half a chunk behind) against all eight waves in lockstep, measured per shape in one process
+// (tools/swin_bench.py, us per launch, lockstep -> staggered): C = 192 MLP 1137 -> 1064 but projection + MLP 1315 -> 1477
+// (the combined kernel spills once the half-steps split its loop); C = 64 487 -> 548 and 559 -> 740; C = 128 369 -> 392 and
+// 434 -> 438; C = 256 314 -> 276 and 339 -> 328.  So: staggered for C = 256 and for the C = 192 MLP, lockstep otherwise.
+// ELVIS_SWIN_STAGGER=0/1 forces it off / on for A/B runs (read once).
+static int stagger_mode() {
+    static const int v = getenv("ELVIS_SWIN_STAGGER") ? atoi(getenv("ELVIS_SWIN_STAGGER")) : -1;
+    return v;
+}
+template <int C, int PXT, int MODE> int launch_swin_s(const SwinArgs& a, hipStream_t stream, bool default_stag) {
+    if constexpr (MODE == 0) return launch_swin<C, PXT, MODE, false>(a, stream);
+    const int m = stagger_mode();
+    const bool st = m < 0 ? default_stag : m != 0;
+    return st ? launch_swin<C, PXT, MODE, true>(a, stream) : launch_swin<C, PXT, MODE, false>(a, stream);
+}
 template <int MODE> int dispatch_swin(int c, const SwinArgs& a, hipStream_t stream) {
     switch (c) {
-        case 64: return launch_swin<64, 2, MODE>(a, stream);
-        case 128: return launch_swin<128, 2, MODE>(a, stream);
-        case 192: return launch_swin<192, 2, MODE>(a, stream);
-        case 256: return launch_swin<256, 1, MODE>(a, stream);    // 128 accumulator registers at two tokens tiles: one
+        case 64: return launch_swin_s<64, 2, MODE>(a, stream, false);
+        case 128: return launch_swin_s<128, 2, MODE>(a, stream, false);
+        case 192: return launch_swin_s<192, 2, MODE>(a, stream, MODE == 1);
+        case 256: return launch_swin_s<256, 1, MODE>(a, stream, true);
         default: break;
     }
     elvis_set_error("elvis_swin: channels must be 64, 128, 192 or 256 (got %d)", c);
