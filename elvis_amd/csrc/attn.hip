@@ -266,6 +266,157 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_mfma_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 3: the same attention with P and O kept in REGISTERS (window_attention_mfma_kernel above moves P, V and the
+// output tile through LDS in 2-byte pieces: 0.32 of its LDS cycles are bank conflicts, 0.34 of the HBM peak).
+//   S^T[key][token] = K Q^T        (A = K, B = Q, both straight from global memory): a lane holds, for its token column,
+//                                   16 keys in registers and the rest in the lanes 16 / 32 / 48 away - the softmax over
+//                                   keys is 16 in-lane values + two cross-lane steps, no DPP row reductions
+//   P^T as B operand               two stacked 16-key accumulator tiles are one 32-deep B fragment (the key order inside
+//                                   it is a permutation; the same one is applied to V's rows when its fragments are read)
+//   O^T[d][token] = V^T P^T        A = V^T through ONE LDS tile stored row-major ([key][32 d], 16-byte writes) and read with
+//                                   ds_read_b64_tr_b16 (hardware transpose); the block columns a lane group reads are
+//                                   d = 8p + 4dt + (0..3), so accumulator rows 4q + r of the two d tiles are d = 8q .. 8q + 7:
+//                                   a token's 64-byte head slice leaves as four 16-byte stores straight from registers
+// The 8-byte halves of a V row's 16-byte chunks are swapped on rows with bit 2 set: the two 4-row blocks a 32-lane half
+// reads (keys 4 apart) then fall on disjoint banks.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const half_t* __restrict__ qkv,
+                                                                  half_t* __restrict__ out, int h, int w,
+                                                                  int heads, int shift, int qkv_pitch,
+                                                                  int out_pitch,
+                                                                  const float* __restrict__ bias_table,
+                                                                  float scale) {
+    __shared__ __attribute__((aligned(16))) half_t sV[ATT_NW][NTOK * HD];
+    __shared__ float sBias[ATT_NW][(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int s_pos[NTOK];
+    __shared__ int s_region[NTOK];
+    const int E = heads * HD;
+    const int nwx = w / WS, nwy = h / WS;
+    int bid = blockIdx.x;
+    const int wx = bid % nwx;
+    bid /= nwx;
+    const int wy = bid % nwy;
+    const int n = bid / nwy;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid < NTOK) {
+        int ty = tid / WS, tx = tid % WS;
+        int yr = wy * WS + ty, xr = wx * WS + tx;
+        int y = yr + shift, x = xr + shift;
+        if (y >= h) y -= h;
+        if (x >= w) x -= w;
+        s_pos[tid] = (n * h + y) * w + x;
+        int rh = 0, rw = 0;
+        if (shift) {
+            rh = yr < h - WS ? 0 : (yr < h - shift ? 1 : 2);
+            rw = xr < w - WS ? 0 : (xr < w - shift ? 1 : 2);
+        }
+        s_region[tid] = rh * 3 + rw;
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, lq = lane >> 4;
+    half_t* myV = sV[wave];
+    float* myB = sBias[wave];
+    // transposed-read addressing: lane 4 qq + p of a 16-lane group supplies block row qq, columns 4p .. 4p+3
+    const int qq = (lane & 15) >> 2, pp = lane & 3;
+    const int swz = lq & 1;                                 // bit 2 of the key rows 32 m + 16 s + 4 lq + qq this lane addresses
+
+    for (int head = wave; head < heads; head += ATT_NW) {
+        for (int t = lane; t < (2 * WS - 1) * (2 * WS - 1); t += 64) myB[t] = bias_table[t * heads + head];
+        // V tile (64 keys x 32 dims) -> LDS, row-major, 16-byte writes
+        for (int t = lane; t < NTOK * 4; t += 64) {
+            const int j = t >> 2, c = t & 3;
+            uint4 v = *reinterpret_cast<const uint4*>(qkv + (long long)s_pos[j] * qkv_pitch + 2 * E + head * HD + c * 8);
+            if (j & 4) v = make_uint4(v.z, v.w, v.x, v.y);
+            *reinterpret_cast<uint4*>(myV + j * HD + c * 8) = v;
+        }
+        half8 fq[4], fk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tok = t * 16 + lr;
+            fq[t] = *reinterpret_cast<const half8*>(qkv + (long long)s_pos[tok] * qkv_pitch + head * HD + lq * 8);
+            fk[t] = *reinterpret_cast<const half8*>(qkv + (long long)s_pos[tok] * qkv_pitch + E + head * HD + lq * 8);
+        }
+        float4v sacc[4][4];   // [key tile][token tile]: rows = keys jt*16 + 4 lq + r, column = token it*16 + lr
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                sacc[jt][it] = (float4v){0.f, 0.f, 0.f, 0.f};
+                sacc[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fk[jt], fq[it], sacc[jt][it], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // the bias column and the V tile have landed (wave-local LDS)
+        __builtin_amdgcn_wave_barrier();
+        half8 pb[4][2];       // P^T as B fragments: [token tile][32-key block]
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = it * 16 + lr;
+            const int yi = i / WS, xi = i % WS;
+            const int reg_i = s_region[i];
+            float v[4][4];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + lq * 4 + r;
+                    const int yj = j / WS, xj = j % WS;
+                    float a = sacc[jt][it][r] * scale + myB[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)];
+                    if (shift && s_region[j] != reg_i) a += -100.0f;
+                    v[jt][r] = a;
+                    mx = fmaxf(mx, a);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[jt][r] = __expf(v[jt][r] - mx);
+                    sum += v[jt][r];
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pb[it][m][jj] = (half_t)(v[2 * m + (jj >> 2)][jj & 3] * inv);
+        }
+        float4v oacc[2][4];   // [d tile][token tile]: rows 4 lq + r of d tile dt = dims 8 lq + 4 dt + r
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) oacc[dt][it] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                // element jj of the A fragment: key 32 m + 16 (jj >> 2) + 4 lq + (jj & 3), dim 8 p + 4 dt + e of column 4 p + e
+                const half_t* base = myV + (32 * m + 4 * lq + qq) * HD + 8 * pp + 4 * (dt ^ swz);
+                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)base);
+                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 16 * HD));
+                half8 vt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vt[e] = (half_t)lo[e]; vt[4 + e] = (half_t)hi[e]; }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) oacc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[it][m], oacc[dt][it], 0, 0, 0);
+            }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            half8 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = (half_t)oacc[0][it][r]; o[4 + r] = (half_t)oacc[1][it][r]; }
+            *reinterpret_cast<half8*>(out + (long long)s_pos[it * 16 + lr] * out_pitch + head * HD + lq * 8) = o;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();   // the next head reuses this wave's LDS tiles
+    }
+}
+
 }  // namespace
 
 extern "C" int elvis_window_attention(const void* qkv, void* out, int dtype, int n, int h, int w, int heads,
@@ -282,8 +433,13 @@ extern "C" int elvis_window_attention(const void* qkv, void* out, int dtype, int
     if (dtype == ELVIS_F16 && !attn_valu) {
         // MFMA path: one workgroup per window, waves loop over heads
         long long wblocks = (long long)n * (h / ws) * (w / ws);
-        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)wblocks), dim3(64 * ATT_NW), 0, (hipStream_t)stream,
-                           (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);
+        static const bool lds_form = getenv("ELVIS_ATTN_LDS") != nullptr;   // A/B switch: round 2's P / O through LDS
+        if (lds_form)
+            hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)wblocks), dim3(64 * ATT_NW), 0, (hipStream_t)stream,
+                               (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);
+        else
+            hipLaunchKernelGGL(window_attention_tr_kernel, dim3((unsigned)wblocks), dim3(64 * ATT_NW), 0, (hipStream_t)stream,
+                               (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);
     } else if (dtype == ELVIS_F16)
         hipLaunchKernelGGL(window_attention_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const half_t*)qkv, (half_t*)out, h, w, heads, shift, qkv_pitch, out_pitch, bias_table, scale);

@@ -39,3 +39,20 @@ for name, c, hid, n, h, w in SHAPES:
         fl = (4.0 * c * hid + (2.0 * c * c if kind == "proj_mlp" else 0)) * tok if kind != "ln_qkv" else 2.0 * c * 3 * c * tok
         by = (3 if kind == "mlp" else 3 if kind == "proj_mlp" else 4) * c * 2.0 * tok
         print(f"{name:18s} {kind:9s} {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TFLOP/s  {by/t/1e6:7.1f} GB/s algorithmic", flush=True)
+
+# window attention on the same token images (qkv = 3C channels): ELVIS_ATTN_LDS=1 selects round 2's kernel
+for name, c, hid, n, h, w in SHAPES:
+    heads = c // 32
+    qkv = ops.Act(torch.randn((n, h, w, 3 * c), device=dev, dtype=torch.float16), 3 * c)
+    table = torch.randn((225, heads), device=dev) * 0.5
+    for shift in (0, 4):
+        ops.window_attention(qkv, heads, 32, 8, shift, table, 32 ** -0.5)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); ops.window_attention(qkv, heads, 32, 8, shift, table, 32 ** -0.5); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        t = sorted(ts)[2]
+        by = 4 * c * 2.0 * n * h * w
+        print(f"{name:18s} attention shift {shift}  {t*1e3:8.1f} us  {by/t/1e6:7.1f} GB/s algorithmic", flush=True)
