@@ -51,6 +51,7 @@ SIGNATURES = {
     "elvis_conv_stats_tiles": [C.POINTER(ConvDesc)],
     "elvis_conv_kernel_name": [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t],
     "elvis_conv_x3_eligible": [C.POINTER(ConvDesc)],
+    "elvis_conv_debug_set": [C.c_char_p, i32],
     "elvis_gn_partials_to_sums": [vp, i32, i32, i32, vp, i32, i32, vp],
     "elvis_groupnorm_workspace_floats": [i32, i32, i32, i32],
     "elvis_groupnorm_sums": [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp],

@@ -1,6 +1,7 @@
 // C ABI of the conv kernels (elvis_conv2d and friends) + the f16 instantiations; the fp32 / compensated-f16
 // instantiations live in conv_f32.hip.  Kernels, launch helpers and dispatch rules: conv_kernels.inc.
 #include "conv_kernels.inc"
+#include <string.h>
 
 // conv_f32.hip: halo != 0 -> launch_halo<float, tco>, else dispatch<float>(id)
 __attribute__((visibility("hidden"))) int elvis_conv_launch_f32_(const void* conv_args, int halo, int tco, int id, hipStream_t stream);
@@ -8,10 +9,19 @@ __attribute__((visibility("hidden"))) int elvis_conv_launch_f32_(const void* con
 __attribute__((visibility("hidden"))) int elvis_conv_pack_x3p_(const float* w_oihw, void* packed, int cout, int ctot, int nkc, int n_co_tiles,
                                                               int tco, int taps, hipStream_t stream);
 
-// A/B switches of the experiment tools: read ONCE per process, never on the per-call path
+// A/B switches of the experiment tools: the environment is read ONCE per process, never on the per-call path;
+// elvis_conv_debug_set() flips the same switches at run time (tests compare the halo kernels with the generic one).
+#include <atomic>
+static std::atomic<int> g_no_halo{-1};
 static bool no_halo() {
-    static const bool v = getenv("ELVIS_NO_HALO") != nullptr;
-    return v;
+    static const bool env = getenv("ELVIS_NO_HALO") != nullptr;
+    const int v = g_no_halo.load(std::memory_order_relaxed);
+    return v < 0 ? env : v != 0;
+}
+extern "C" int elvis_conv_debug_set(const char* key, int value) {
+    ELVIS_REQUIRE(key, "elvis_conv_debug_set: null key");
+    if (!strcmp(key, "no_halo")) { g_no_halo.store(value, std::memory_order_relaxed); return ELVIS_OK; }   // -1: back to the environment
+    ELVIS_REQUIRE(false, "elvis_conv_debug_set: unknown key '%s'", key);
 }
 static int strip_width() {
     static const int v = getenv("ELVIS_STRIP") ? atoi(getenv("ELVIS_STRIP")) : 8;   // 0 = row-major tile walk

@@ -195,6 +195,15 @@ class PackedConv:
         assert kh == kw and ctot == cin + cin2
         self.cin, self.cin2, self.cout, self.ksize = cin, cin2, cout, kh
         self.dtype, self.device = dtype, device
+        # A ragged output count (189, 3, 1 ...) is padded to whole 4-channel groups with zero weights and zero bias: the extra
+        # channels ARE pad channels of the output activation (zero either way), and the kernels then run their branch-free
+        # epilogue instead of the ragged one (per-element bias loads and 2-byte stores: ~40 k cycles per tile - the DCT slot's
+        # 32 -> 189 conv went from 3.7 to 2.0 ms).  `cout` stays the logical count; `cout_k` is what the kernels see.
+        self.cout_k = (cout + 3) // 4 * 4
+        if self.cout_k != cout:
+            weight_oihw = torch.cat([weight_oihw, weight_oihw.new_zeros((self.cout_k - cout, ctot, kh, kw))], 0)
+            if bias is not None:
+                bias = torch.cat([bias, bias.new_zeros(self.cout_k - cout)], 0)
         # fp32 tensors, products on the f16 matrix pipe with the rounding error compensated (ELVIS_F32X3, conv.hip
         # mma_tile_x): ~1e-6 relative instead of f16's 5e-4, at about twice the fp32 MFMA's speed
         self.x3 = bool(_X3_DEFAULT if x3 is None else x3) and dtype == torch.float32
@@ -202,7 +211,7 @@ class PackedConv:
         d.dtype = L.dtype_code(dtype)
         d.n = d.h = d.w = d.ho = d.wo = 1
         d.cin, d.cin_pitch, d.cin2, d.cin2_pitch = cin, pitch_for(cin), cin2, pitch_for(cin2) if cin2 else 0
-        d.cout, d.cout_pitch = cout, pitch_for(cout)
+        d.cout, d.cout_pitch = self.cout_k, pitch_for(cout)
         d.ksize, d.stride = kh, 1
         if kh == 2:   # one parity of a sub-pixel upsample conv (PackedUpConv): h x w -> 2h x 2w
             d.subpixel, d.ho, d.wo = 1, 2, 2
@@ -251,7 +260,7 @@ class PackedConv:
         d.ho, d.wo = ho, wo
         if out is None:   # (the conv kernels write the pad channels themselves: no zero-fill pass)
             out = new_act(x.n, ho, wo, self.cout, x.t.dtype, x.t.device, zero=False)
-        d.cout, d.cout_pitch = self.cout, out.pitch
+        d.cout, d.cout_pitch = self.cout_k, out.pitch
         pa = pb = None
         if prologue is not None:
             pa, pb = prologue
@@ -260,7 +269,7 @@ class PackedConv:
         packed = self.weights_for(d)
         tiles = lib().elvis_conv_stats_tiles(C.byref(d))
         if want_stats and tiles > 0:
-            stats = torch.empty((tiles, self.cout, 2), dtype=torch.float32, device=x.t.device)
+            stats = torch.empty((tiles, self.cout_k, 2), dtype=torch.float32, device=x.t.device)
         out.stats = stats
         prof = CONV_PROFILER
         if prof is not None:
@@ -277,6 +286,8 @@ class PackedConv:
             if CONV_SHAPES is not None:
                 CONV_SHAPES.append((x.n, x.h, x.w, self.cin + self.cin2, self.cout, self.ksize, stride,
                                     prologue is not None, residual is not None))
+        if stats is not None and self.cout_k != self.cout:   # padded count: the consumers read [tiles, cout, 2] rows
+            out.stats = stats[:, :self.cout].contiguous()
         return out
 
 
@@ -350,7 +361,7 @@ class PackedUpConv:
             d.cin, d.cin_pitch = x.c, x.pitch
             d.ksize, d.stride, d.subpixel, d.act = 2, 1, 1 + k, act
             d.ho, d.wo = 2 * h, 2 * w
-            d.cout, d.cout_pitch = self.cout, out.pitch
+            d.cout, d.cout_pitch = conv.cout_k, out.pitch
             packed = conv.weights_for(d)
             tiles = lib().elvis_conv_stats_tiles(C.byref(d))
             if want_stats and stats is None:

@@ -182,6 +182,10 @@ int elvis_conv_stats_tiles(const elvis_conv_desc* d);
  * into buf (NUL-terminated, truncated to n).  For per-kernel profiling (bench.py roofline). */
 int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_t n);
 
+/* Test / experiment switch: "no_halo" = 1 routes every conv to the generic implicit-GEMM kernel (what the environment
+ * variable ELVIS_NO_HALO does for a whole process), 0 forces the halo kernels, -1 returns to the environment's choice. */
+int elvis_conv_debug_set(const char* key, int value);
+
 /* 1 when a descriptor with dtype ELVIS_F32X3 has a compensated-f16 kernel (3x3 stride 1 / sub-pixel 2x2 / 1x1 on the
  * halo-tile kernels with a 64- or 128-channel output tile), else 0.  ELVIS_F32X3 weights are packed by
  * elvis_conv_pack_weights as f16 (hi, lo) parts - planes of 32 channels for 3x3 layers (three MFMAs per 32 channels),

@@ -145,13 +145,18 @@ def test_conv_halo_fused(gpu_device, dtype, cfg):
     gd = got.double()
     assert torch.allclose(s[:, :, 0], gd.sum((2, 3)), rtol=1e-5, atol=1e-2)
     assert torch.allclose(s[:, :, 1], (gd * gd).sum((2, 3)), rtol=1e-5, atol=1e-2)
-    # and the same conv without the halo kernel (ELVIS_NO_HALO=1 is read per call)
-    import os
-    os.environ["ELVIS_NO_HALO"] = "1"
+    # and the same conv on the generic implicit-GEMM kernel (the run-time form of ELVIS_NO_HALO=1)
+    d = ops.ConvDesc()
+    d.dtype, d.n, d.h, d.w, d.ho, d.wo = ops.L.dtype_code(dtype), n, h, w, ho, wo
+    d.cin, d.cin_pitch, d.cin2, d.cin2_pitch = c1, a1.pitch, c2, (a2.pitch if c2 else 0)
+    d.cout, d.cout_pitch, d.ksize, d.stride, d.pad_before, d.upsample, d.prologue = conv.cout_k, y.pitch, 3, 1, 1, int(ups), 1
+    assert ops.conv_kernel_name(d).startswith("conv3x3_halo")
+    check(lib().elvis_conv_debug_set(b"no_halo", 1))
     try:
+        assert ops.conv_kernel_name(d).startswith("conv_igemm")
         y0 = conv(a1, a2, upsample=ups, prologue=(pa.to(gpu_device), pb.to(gpu_device)), residual=ar)
     finally:
-        del os.environ["ELVIS_NO_HALO"]
+        check(lib().elvis_conv_debug_set(b"no_halo", -1))
     assert (_nchw(y0) - got).abs().max().item() < TOL[dtype]
 
 
