@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __rest
         }
     }
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const float fgy = (float)gy, fgx = (float)gx, fh2 = (float)h + 2.0f, fw2 = (float)w + 2.0f;
     constexpr int mask_h0 = 18 * cin;                                      // first mask half
     static_assert(((mask_h0 + 9 * cin - 1) >> 1) < 4 * n16 && 9 * cin <= 4 * n16, "offset / mask row does not cover every (group, tap)");
     unsigned pk[4];                                                        // eight packed samples
@@ -172,12 +173,15 @@ __global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __rest
             const int mh = mask_h0 + kk;
             const half2v mm = __builtin_bit_cast(half2v, omw[mh >> 1]);    // static index (kk < K: inside the row)
             float m = (float)mm[mh & 1];
-            if (mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
-            const float sy = (float)(gy + tap / 3 - 1) + (float)d[0], sx = (float)(gx + tap % 3 - 1) + (float)d[1];
+            // (this kernel is VALU-bound - 63 samples per pixel, SQ_ACTIVE_INST_VALU 38 % of the wave cycles at two waves per
+            //  SIMD - so the sigmoid is the 4-instruction exp2 / rcp form: ~1e-6 relative, far below the f16 storage of the
+            //  samples; the clamps are one v_med3 each)
+            if (mask_sigmoid) m = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
+            const float sy = (fgy + (float)(tap / 3 - 1)) + (float)d[0], sx = (fgx + (float)(tap % 3 - 1)) + (float)d[1];
             const float fy = floorf(sy), fx = floorf(sx);
             const float ly = sy - fy, lx = sx - fx;
             // clamp far-away samples (they contribute zero anyway) so the int conversion cannot overflow
-            const int y0 = (int)fminf(fmaxf(fy, -4.0f), (float)h + 2.0f), x0 = (int)fminf(fmaxf(fx, -4.0f), (float)w + 2.0f);
+            const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -4.0f, fh2), x0 = (int)__builtin_amdgcn_fmed3f(fx, -4.0f, fw2);
             const int wy = y0 - y00, wx = x0 - x00;
             float v00, v01, v10, v11;
             if (wy >= 0 && wy < WY_ - 1 && wx >= 0 && wx < WX_ - 1) {      // all four corners inside the LDS window
