@@ -528,9 +528,10 @@ class SwinFused:
     @staticmethod
     def proj_pays(c: int) -> bool:
         """Folding the projection in front of the MLP, against projection + MLP as two kernels (tools/swin_bench.py, us per
-        launch): 559 vs ~890 at C = 64 (1080p), 434 vs ~570 at 128, 328 vs ~380 at 256, 1315 vs ~1700 at 192 (where the
-        combined kernel spills around its LayerNorm, outside the chunk loop) - it pays everywhere."""
-        return True
+        launch on the largest level): 559 vs ~890 at C = 64 (1080p), 434 vs ~570 at 128, 328 vs ~380 at 256.  At C = 192 the
+        combined kernel sits at 256 VGPRs (96 spilled around its LayerNorm) and cannot take the staggered MLP loop: over the
+        SinSR step's 216 launches it averages 990 us against 769 (MLP, lockstep; ~720 staggered) + 195 (projection) - not there."""
+        return c != 192
 
     def __init__(self, norm_w, norm_b, w1, b1, w2=None, b2=None, *, proj_w=None, proj_b=None, device, eps: float = 1e-5):
         n1, c = w1.shape[0], w1.shape[1]
