@@ -19,6 +19,7 @@
 //    32-byte-per-lane NHWC stores.  HBM-bound by design: 378 B of offsets/masks in, 128 B out per pixel.
 //  * dcnv2_kernel (any dtype / grouping): the generic scalar form - the fp32 exact mode and odd shapes.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <mutex>
 
@@ -135,10 +136,20 @@ __global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __rest
     }
     for (int i = tid; i < ksteps * IMG_BYTES / 4; i += 256) reinterpret_cast<unsigned*>(wimg)[i] = 0u;
     __syncthreads();
-    for (int i = tid; i < cout * K; i += 256) {
-        const int co = i / K, k = i - co * K;
-        const int row = ((co & 15) >> 2) * 16 + (co >> 4) * 4 + (co & 3);
-        *reinterpret_cast<half_t*>(wimg + (k >> 5) * IMG_BYTES + img_off(row, (k & 31) >> 3) + (k & 7) * 2) = wt[i];
+    {   // [cout][K] halfs, read as 16-byte vectors (the host checks the pointer's alignment) and scattered by element:
+        // two vector loads per thread instead of sixteen 2-byte ones on every workgroup's start-up path
+        auto put = [&](int i, half_t v) {
+            const int co = i / K, k = i - co * K;
+            const int row = ((co & 15) >> 2) * 16 + (co >> 4) * 4 + (co & 3);
+            *reinterpret_cast<half_t*>(wimg + (k >> 5) * IMG_BYTES + img_off(row, (k & 31) >> 3) + (k & 7) * 2) = v;
+        };
+        const int nv = (cout * K) >> 3;
+        for (int i = tid; i < nv; i += 256) {
+            const half8 v = *reinterpret_cast<const half8*>(wt + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) put(8 * i + e, v[e]);
+        }
+        for (int i = 8 * nv + tid; i < cout * K; i += 256) put(i, wt[i]);
     }
 
     // ---- phase 1: one pixel per thread
@@ -162,48 +173,76 @@ __global__ __launch_bounds__(256, 2) void dcnv2_tile_kernel(const half_t* __rest
     const float fgy = (float)gy, fgx = (float)gx, fh2 = (float)h + 2.0f, fw2 = (float)w + 2.0f;
     constexpr int mask_h0 = 18 * cin;                                      // first mask half
     static_assert(((mask_h0 + 9 * cin - 1) >> 1) < 4 * n16 && 9 * cin <= 4 * n16, "offset / mask row does not cover every (group, tap)");
-    unsigned pk[4];                                                        // eight packed samples
     const int prow = lane;                                                 // this pixel's row in the wave's images
+    // Offsets of at most 6 pixels keep every corner of every tap inside the LDS window (|tap| <= 1, halo 8, the
+    // window check below then always passes): a wave whose 64 pixels all satisfy that - every wave of the DCT slot,
+    // whose offsets are a fraction of a pixel - runs the sample loop WITHOUT the window test and without the global-read
+    // path.  That loop is a quarter of the other's code (the fully unrolled bounds-checked reads are ~8 k instructions,
+    // more than the instruction cache holds) and saves eight VALU per sample.
+    bool small = true;
+    {
+        // on the BIT PATTERNS of |dy|, |dx|: for non-negative halfs integer order is value order, and inf / NaN
+        // (>= 0x7c00) compare as the largest values - they take the checked path, whose clamps handle them
+        typedef unsigned short ushort2w __attribute__((ext_vector_type(2)));
+        ushort2w mx = {0, 0};
 #pragma unroll
-    for (int kk = 0; kk < ksteps * 32; ++kk) {                             // k = g*9 + tap (one channel per group)
-        const int g = kk / 9, tap = kk - g * 9;
-        float v = 0.f;
-        if (kk < K) {
-            const half2v d = __builtin_bit_cast(half2v, omw[kk]);          // (dy, dx) = halfs 2kk, 2kk + 1
-            const int mh = mask_h0 + kk;
-            const half2v mm = __builtin_bit_cast(half2v, omw[mh >> 1]);    // static index (kk < K: inside the row)
-            float m = (float)mm[mh & 1];
-            // (this kernel is VALU-bound - 63 samples per pixel, SQ_ACTIVE_INST_VALU 38 % of the wave cycles at two waves per
-            //  SIMD - so the sigmoid is the 4-instruction exp2 / rcp form: ~1e-6 relative, far below the f16 storage of the
-            //  samples; the clamps are one v_med3 each)
-            if (mask_sigmoid) m = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
-            const float sy = (fgy + (float)(tap / 3 - 1)) + (float)d[0], sx = (fgx + (float)(tap % 3 - 1)) + (float)d[1];
-            const float fy = floorf(sy), fx = floorf(sx);
-            const float ly = sy - fy, lx = sx - fx;
-            // clamp far-away samples (they contribute zero anyway) so the int conversion cannot overflow
-            const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -4.0f, fh2), x0 = (int)__builtin_amdgcn_fmed3f(fx, -4.0f, fw2);
-            const int wy = y0 - y00, wx = x0 - x00;
-            float v00, v01, v10, v11;
-            if (wy >= 0 && wy < WY_ - 1 && wx >= 0 && wx < WX_ - 1) {      // all four corners inside the LDS window
-                const float* c0 = xin + g * WP_ + wy * WX_ + wx;
-                v00 = c0[0]; v01 = c0[1]; v10 = c0[WX_]; v11 = c0[WX_ + 1];
-            } else {                                                       // rare: bounds-checked global reads
-                auto tapg = [&](int yy, int xx) -> float {
-                    return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (float)xb[((long long)yy * w + xx) * x_pitch + g] : 0.f;
-                };
-                v00 = tapg(y0, x0); v01 = tapg(y0, x0 + 1); v10 = tapg(y0 + 1, x0); v11 = tapg(y0 + 1, x0 + 1);
-            }
-            v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-            v *= m;
-            if (!pok) v = 0.f;
-        }
-        {   // pack two samples per dword, store eight per 16-byte chunk
-            const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (half_t)v);
-            if ((kk & 1) == 0) pk[(kk & 7) >> 1] = hb; else pk[(kk & 7) >> 1] |= hb << 16;
-            if ((kk & 7) == 7 && (kk >> 5) < ksteps)
-                *reinterpret_cast<uint4*>(col + (kk >> 5) * IMG_BYTES + img_off(prow, (kk & 31) >> 3)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        }
+        for (int kk = 0; kk < K; ++kk)
+            mx = __builtin_elementwise_max(mx, __builtin_bit_cast(ushort2w, omw[kk] & 0x7fff7fffu));
+        small = mx[0] <= 0x4600 && mx[1] <= 0x4600;   // 6.0 in f16
     }
+    const bool wave_small = __builtin_amdgcn_ballot_w64(!small) == 0ull;
+    auto sample_loop = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
+        unsigned pk[4];                                                    // eight packed samples
+#pragma unroll
+        for (int kk = 0; kk < ksteps * 32; ++kk) {                         // k = g*9 + tap (one channel per group)
+            const int g = kk / 9, tap = kk - g * 9;
+            float v = 0.f;
+            if (kk < K) {
+                const half2v d = __builtin_bit_cast(half2v, omw[kk]);      // (dy, dx) = halfs 2kk, 2kk + 1
+                const int mh = mask_h0 + kk;
+                const half2v mm = __builtin_bit_cast(half2v, omw[mh >> 1]);   // static index (kk < K: inside the row)
+                float m = (float)mm[mh & 1];
+                // (this kernel is VALU-bound - 63 samples per pixel - so the sigmoid is the 4-instruction exp2 / rcp form:
+                //  ~1e-6 relative, far below the f16 storage of the samples; the clamps are one v_med3 each)
+                if (mask_sigmoid) m = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
+                const float sy = (fgy + (float)(tap / 3 - 1)) + (float)d[0], sx = (fgx + (float)(tap % 3 - 1)) + (float)d[1];
+                const float fy = floorf(sy), fx = floorf(sx);
+                const float ly = sy - fy, lx = sx - fx;
+                float v00, v01, v10, v11;
+                if constexpr (CHECK) {
+                    // clamp far-away samples (they contribute zero anyway) so the int conversion cannot overflow
+                    const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -4.0f, fh2), x0 = (int)__builtin_amdgcn_fmed3f(fx, -4.0f, fw2);
+                    const int wy = y0 - y00, wx = x0 - x00;
+                    if (wy >= 0 && wy < WY_ - 1 && wx >= 0 && wx < WX_ - 1) {  // all four corners inside the LDS window
+                        const float* c0 = xin + g * WP_ + wy * WX_ + wx;
+                        v00 = c0[0]; v01 = c0[1]; v10 = c0[WX_]; v11 = c0[WX_ + 1];
+                    } else {                                                   // rare: bounds-checked global reads
+                        auto tapg = [&](int yy, int xx) -> float {
+                            return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (float)xb[((long long)yy * w + xx) * x_pitch + g] : 0.f;
+                        };
+                        v00 = tapg(y0, x0); v01 = tapg(y0, x0 + 1); v10 = tapg(y0 + 1, x0); v11 = tapg(y0 + 1, x0 + 1);
+                    }
+                } else {
+                    const int wy = (int)fy - y00, wx = (int)fx - x00;          // inside the window by the offset bound
+                    const float* c0 = xin + g * WP_ + wy * WX_ + wx;
+                    v00 = c0[0]; v01 = c0[1]; v10 = c0[WX_]; v11 = c0[WX_ + 1];
+                }
+                // bilinear blend as three lerps (six instructions; the products-of-weights form was ten)
+                const float a0 = fmaf(lx, v01 - v00, v00), a1 = fmaf(lx, v11 - v10, v10);
+                v = fmaf(ly, a1 - a0, a0);
+                v *= m;
+                if (!pok) v = 0.f;
+            }
+            {   // pack two samples per dword, store eight per 16-byte chunk
+                const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (half_t)v);
+                if ((kk & 1) == 0) pk[(kk & 7) >> 1] = hb; else pk[(kk & 7) >> 1] |= hb << 16;
+                if ((kk & 7) == 7 && (kk >> 5) < ksteps)
+                    *reinterpret_cast<uint4*>(col + (kk >> 5) * IMG_BYTES + img_off(prow, (kk & 31) >> 3)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        }
+    };
+    if (wave_small) sample_loop(std::false_type{}); else sample_loop(std::true_type{});
     __syncthreads();   // weights image complete (written by all threads); the wave's own samples are ordered by lgkmcnt
 
     // ---- phase 2: this wave's 64 pixels x 64 output channels on the matrix cores
@@ -317,7 +356,7 @@ extern "C" int elvis_dcnv2(const void* x, const void* offset_mask, const void* w
     // the tiled gather + MFMA kernel: f16, one channel per deformable group, up to 8 channels, up to 64 outputs
     static const bool no_tile = getenv("ELVIS_DCN_GENERIC") != nullptr;   // A/B switch
     if (dtype == ELVIS_F16 && !no_tile && deformable_groups == cin && (cin == 7 || cin == 8) && x_pitch == 8 && cout <= 64 &&
-        om_pitch % 8 == 0 && om_pitch >= ((27 * cin * 2 + 15) / 16) * 8 && (((uintptr_t)x | (uintptr_t)offset_mask | (uintptr_t)out) & 15) == 0) {
+        om_pitch % 8 == 0 && om_pitch >= ((27 * cin * 2 + 15) / 16) * 8 && (((uintptr_t)x | (uintptr_t)offset_mask | (uintptr_t)out | (uintptr_t)weight) & 15) == 0) {
         const int ksteps = (K + 31) / 32;
         const int tiles_x = (w + TX_ - 1) / TX_, tiles_y = (h + TY_ - 1) / TY_;
         const size_t lds2 = XIN_BYTES + (size_t)ksteps * IMG_BYTES * 5;

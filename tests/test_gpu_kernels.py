@@ -103,6 +103,13 @@ def test_conv_concat_residual_act_prologue(gpu_device, dtype):
     (64, 0, 32, 17, 35, False),       # 32-channel output tile
     (128, 0, 128, 64, 1920, False),   # the dominant instantiation at full 1080p width: XCD remap, 60 tiles per row
     (64, 0, 64, 72, 1920, False),     # >= 128 K pixels per image: the 16-row ("tall") 64-channel tile
+    # whole 32-pixel tile columns + whole cout tiles
+    (128, 0, 128, 21, 64, False),     # ragged bottom edge only
+    (256, 0, 256, 12, 32, False),     # two cout tiles, eight K chunks, one tile column
+    (32, 0, 128, 16, 64, False),      # a single K chunk
+    (64, 0, 64, 20, 96, False),       # 64-channel tile, whole tile columns
+    (32, 0, 512, 40, 96, False),      # four cout tiles: the grouped block walk (decode_block, co_group = 2), 30 pixel tiles over 8 XCDs
+    (32, 0, 320, 17, 64, False),      # five 64-channel cout tiles: the last group is narrower
 ])
 def test_conv_halo_fused(gpu_device, dtype, cfg):
     """The halo kernel with everything fused: GN-affine+SiLU prologue, bias, residual, and the

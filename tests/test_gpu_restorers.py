@@ -18,14 +18,19 @@ def _act(x_nchw, dtype, dev):
     return a
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float16, 2e-2)])
-def test_dcnv2_kernel(gpu_device, dtype, tol):
+@pytest.mark.parametrize("dtype,tol,off_scale", [(torch.float32, 1e-4, 2.0), (torch.float16, 2e-2, 2.0),
+                                                 (torch.float16, 2e-2, 0.5),    # every offset <= 6 px: the tiled kernel's unchecked sample loop
+                                                 (torch.float16, 2e-2, -1.0)])  # small in the top rows only: both loops in one launch
+def test_dcnv2_kernel(gpu_device, dtype, tol, off_scale):
     from elvis_amd import ops
     from oracle import restorers_ref as R
     g = torch.Generator().manual_seed(21)
     n, c, h, w, G, co = 2, 7, 19, 23, 7, 64
     x = torch.rand(n, c, h, w, generator=g)
-    off = torch.randn(n, 18 * G, h, w, generator=g) * 2.0          # up to several pixels, leaves the image at borders
+    off = torch.randn(n, 18 * G, h, w, generator=g) * abs(off_scale)   # 2.0: up to several pixels, leaves the image at borders
+    if off_scale < 0:
+        off *= 3.0
+        off[:, :, :9] *= 0.1
     mlog = torch.randn(n, 9 * G, h, w, generator=g)
     wt = torch.randn(co, c, 3, 3, generator=g) / 8
     b = torch.randn(co, generator=g) * 0.1
