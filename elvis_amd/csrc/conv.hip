@@ -1,6 +1,7 @@
 // C ABI of the conv kernels (elvis_conv2d and friends) + the f16 instantiations; the fp32 / compensated-f16
 // instantiations live in conv_f32.hip.  Kernels, launch helpers and dispatch rules: conv_kernels.inc.
 #include "conv_kernels.inc"
+#include "conv_ws.inc"
 #include <string.h>
 
 // conv_f32.hip: halo != 0 -> launch_halo<float, tco>, else dispatch<float>(id)
@@ -96,7 +97,10 @@ extern "C" int elvis_conv_kernel_name(const elvis_conv_desc* d, char* buf, size_
     ELVIS_REQUIRE(buf && n > 0, "elvis_conv_kernel_name: null buffer");
     const char* t = d->dtype == ELVIS_F16 ? "half" : "float";
     TileCfg c = choose_tile(d->cout);
-    if (halo_eligible(d) && !no_halo()) {
+    if (ws_shape_ok(d) && !no_halo()) {   // (a call with a residual or a statistics buffer falls back to the halo kernel below)
+        const int nkc = (d->cin + 31) / 32 + (d->cin2 > 0 ? (d->cin2 + 31) / 32 : 0);
+        snprintf(buf, n, "conv3x3_ws_kernel<%d,%d,%s>", nkc, c.tco, ws_stagger(nkc, c.tco) ? "true" : "false");
+    } else if (halo_eligible(d) && !no_halo()) {
         const bool pro = d->ksize == 3 && d->prologue;
         if (x3_planar_run(d))
             snprintf(buf, n, "conv3x3_x3p_kernel<%d,%d,%d,%s,%s>", c.tco, halo_ty(d), d->ksize, pro ? "true" : "false", d->act ? "true" : "false");
@@ -166,6 +170,13 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.two = (halo_two(d) || halo_g1(d)) ? 1 : 0;
     a.tall = (halo_two(d) && halo_tall(d)) ? 1 : 0;
     a.tiles_y = ((subpix ? d->h : d->ho) + tyv - 1) / tyv;
+    if (ws_shape_ok(d) && !residual && !stats && !no_halo()) {   // narrow layer, large image: persistent weight-stationary kernel
+        ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
+        ConvArgs b = a;
+        b.tiles_x = (d->wo + 31) / 32;
+        b.tiles_y = (d->ho + 7) / 8;
+        return dispatch_ws(b, t.tco, (hipStream_t)stream);
+    }
     if (halo_eligible(d) && !no_halo()) {
         ELVIS_REQUIRE((long long)d->n * d->h * d->w < 0x7fffffffLL, "conv: input too large for 32-bit pixel indices");
         hipStream_t st = (hipStream_t)stream;

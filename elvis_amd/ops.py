@@ -282,7 +282,14 @@ class PackedConv:
         if prof is not None:
             e1.record()
             flops = 2.0 * self.ksize * self.ksize * (self.cin + self.cin2) * self.cout * x.n * ho * wo
-            prof.append((conv_kernel_name(d), flops, e0, e1))
+            name = conv_kernel_name(d)
+            if name.startswith("conv3x3_ws_kernel") and residual is None and KERNEL_PROFILER is not None:
+                # the weight-stationary kernel serves narrow layers, which are HBM-bound (csrc/conv_ws.inc): priced against
+                # the bytes it has to move - every input channel read once, every output channel written once
+                nbytes = float(self.cin + self.cin2 + self.cout) * x.t.element_size() * x.n * ho * wo
+                KERNEL_PROFILER.append((name, "hbm", nbytes, e0, e1))
+            else:
+                prof.append((name, flops, e0, e1))
             if CONV_SHAPES is not None:
                 CONV_SHAPES.append((x.n, x.h, x.w, self.cin + self.cin2, self.cout, self.ksize, stride,
                                     prologue is not None, residual is not None))

@@ -618,3 +618,49 @@ def test_conv_writes_its_pad_channels(gpu_device, dtype, cin, cout, k, stride):
     assert torch.count_nonzero(y.t[..., cout:]).item() == 0 and not torch.isnan(y.t).any()
     ref = F.conv2d(x.to(dtype).float(), wt.to(dtype).float(), b, stride=stride, padding=k // 2)
     assert (_nchw(y) - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize("cfg", [
+    # c1, c2, cout, h, w, act   (narrow f16 3x3 layers on >= 128 K pixels: the persistent weight-stationary kernel, conv_ws.inc)
+    (64, 0, 64, 270, 500, 3),     # the DCT slot's quality conv; ragged right and bottom edges, odd tile count
+    (32, 32, 32, 264, 512, 3),    # virtual concat: one K chunk per input
+    (7, 0, 32, 264, 512, 3),      # cin below one K chunk (pitch 8)
+    (32, 0, 189, 264, 512, 0),    # three 64-channel cout tiles, ragged cout padded to 192
+    (64, 0, 1, 264, 512, 0),      # 16-channel tile, one real channel
+])
+def test_conv_weight_stationary(gpu_device, cfg):
+    from elvis_amd import ops
+    c1, c2, cout, h, w, act = cfg
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(31)
+    n = 2
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
+    ctot = c1 + c2
+    wt = torch.randn(cout, ctot, 3, 3, generator=g) / math.sqrt(ctot * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = ops.PackedConv(wt, b, dtype, gpu_device, c1, c2)
+    a1 = _act(x1, dtype, gpu_device)
+    a2 = _act(x2, dtype, gpu_device) if c2 else None
+    d = ops.ConvDesc()
+    d.dtype, d.n, d.h, d.w, d.ho, d.wo = ops.L.dtype_code(dtype), n, h, w, h, w
+    d.cin, d.cin_pitch, d.cin2, d.cin2_pitch = c1, a1.pitch, c2, (a2.pitch if c2 else 0)
+    d.cout, d.cout_pitch, d.ksize, d.stride, d.pad_before, d.act = conv.cout_k, ops.pitch_for(cout), 3, 1, 1, act
+    assert ops.conv_kernel_name(d).startswith("conv3x3_ws_kernel")
+    y = conv(a1, a2, act=act)
+    xcat = (torch.cat([x1, x2], 1) if c2 else x1).to(dtype).float()
+    ref = F.conv2d(xcat, wt.to(dtype).float(), b, padding=1)
+    if act == 3:
+        ref = torch.relu(ref)
+    got = _nchw(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL[dtype]
+    assert y.t[..., cout:].abs().max().item() == 0 if y.t.shape[-1] > cout else True   # pad channels are written as zeros
+    # same result as the halo-tile kernels (ELVIS_NO_HALO also switches this kernel off: both fall back to the generic one)
+    from elvis_amd._lib import lib, check
+    check(lib().elvis_conv_debug_set(b"no_halo", 1))
+    try:
+        y0 = conv(a1, a2, act=act)
+    finally:
+        check(lib().elvis_conv_debug_set(b"no_halo", -1))
+    assert (_nchw(y0) - got).abs().max().item() < TOL[dtype]
