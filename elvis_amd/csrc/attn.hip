@@ -317,6 +317,9 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const 
     __syncthreads();
 
     const int lr = lane & 15, lq = lane >> 4;
+    // shifted windows: only the last row / column of windows holds tokens of more than one region (every other window's
+    // tokens are all region 0): the mask compare + select per score runs for those windows alone
+    const bool need_mask = shift && (wy == nwy - 1 || wx == nwx - 1);
     half_t* myV = sV[wave];
     float* myB = sBias[wave];
     // transposed-read addressing: lane 4 qq + p of a 16-lane group supplies block row qq, columns 4p .. 4p+3
@@ -324,7 +327,8 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const 
     const int swz = lq & 1;                                 // bit 2 of the key rows 32 m + 16 s + 4 lq + qq this lane addresses
 
     for (int head = wave; head < heads; head += ATT_NW) {
-        for (int t = lane; t < (2 * WS - 1) * (2 * WS - 1); t += 64) myB[t] = bias_table[t * heads + head];
+        // the softmax runs in the exp2 domain: the bias column is stored times log2(e), the scale carries the same factor
+        for (int t = lane; t < (2 * WS - 1) * (2 * WS - 1); t += 64) myB[t] = bias_table[t * heads + head] * 1.4426950408889634f;
         // V tile (64 keys x 32 dims) -> LDS, row-major, 16-byte writes
         for (int t = lane; t < NTOK * 4; t += 64) {
             const int j = t >> 2, c = t & 3;
@@ -349,7 +353,9 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const 
             }
         __builtin_amdgcn_s_waitcnt(0xC07F);   // the bias column and the V tile have landed (wave-local LDS)
         __builtin_amdgcn_wave_barrier();
-        half8 pb[4][2];       // P^T as B fragments: [token tile][32-key block]
+        half8 pb[4][2];       // P^T as B fragments: [token tile][32-key block] - UNNORMALISED exp2(a - max) in (0, 1]; the 1 / sum
+        float inv[4];         // of a token scales its 8 output values instead of its 64 probabilities
+        const float scale2 = scale * 1.4426950408889634f;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int i = it * 16 + lr;
@@ -363,8 +369,8 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const 
                 for (int r = 0; r < 4; ++r) {
                     const int j = jt * 16 + lq * 4 + r;
                     const int yj = j / WS, xj = j % WS;
-                    float a = sacc[jt][it][r] * scale + myB[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)];
-                    if (shift && s_region[j] != reg_i) a += -100.0f;
+                    float a = fmaf(sacc[jt][it][r], scale2, myB[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)]);
+                    if (need_mask && s_region[j] != reg_i) a += -144.26950408889634f;   // -100 log2(e)
                     v[jt][r] = a;
                     mx = fmaxf(mx, a);
                 }
@@ -375,16 +381,16 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const 
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[jt][r] = __expf(v[jt][r] - mx);
+                    v[jt][r] = __builtin_amdgcn_exp2f(v[jt][r] - mx);
                     sum += v[jt][r];
                 }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
+            inv[it] = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pb[it][m][jj] = (half_t)(v[2 * m + (jj >> 2)][jj & 3] * inv);
+                for (int jj = 0; jj < 8; ++jj) pb[it][m][jj] = (half_t)v[2 * m + (jj >> 2)][jj & 3];
         }
         float4v oacc[2][4];   // [d tile][token tile]: rows 4 lq + r of d tile dt = dims 8 lq + 4 dt + r
 #pragma unroll
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void window_attention_tr_kernel(const 
         for (int it = 0; it < 4; ++it) {
             half8 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { o[r] = (half_t)oacc[0][it][r]; o[4 + r] = (half_t)oacc[1][it][r]; }
+            for (int r = 0; r < 4; ++r) { o[r] = (half_t)(oacc[0][it][r] * inv[it]); o[4 + r] = (half_t)(oacc[1][it][r] * inv[it]); }
             *reinterpret_cast<half8*>(out + (long long)s_pos[it * 16 + lr] * out_pitch + head * HD + lq * 8) = o;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
