@@ -149,8 +149,8 @@ extern "C" int elvis_conv2d(const elvis_conv_desc* d, const void* x, const void*
     a.par_a = subpix ? (d->subpixel - 1) >> 1 : 0;
     a.par_b = subpix ? (d->subpixel - 1) & 1 : 0;
     a.ostr = subpix ? 2 : 1;
-    a.pad2y = subpix ? 1 - a.par_a : 0;
-    a.pad2x = subpix ? 1 - a.par_b : 0;
+    a.pad2y = subpix ? 1 - a.par_a : (s2d ? d->pad_before : 0);   // space-to-depth: pad (0,1,0,1) form 0, pad 1 form 1
+    a.pad2x = subpix ? 1 - a.par_b : (s2d ? d->pad_before : 0);
     a.s2d = s2d ? 1 : 0;
     a.istr = s2d ? 2 : 1;
     a.nkc_c = s2d ? d->cin / 4 / kc_of(d) : 0x3fffffff;

@@ -7,6 +7,7 @@ multiple of 8, pad channels are kept at zero) accompanied by the logical channel
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -14,6 +15,9 @@ import torch
 
 from . import _lib as L
 from ._lib import ConvDesc, check, lib, ptr
+
+
+_NO_S2D = bool(os.environ.get("ELVIS_NO_S2D"))   # A/B switch, read once at import
 
 
 def _s(t: torch.Tensor) -> int:
@@ -410,16 +414,23 @@ class PackedDownConv:
         """f16 with whole 32-channel chunks, or fp32 tensors on the compensated f16 MFMA (16-channel chunks)."""
         return cout >= 64 and ((dtype == torch.float16 and cin % 32 == 0) or (dtype == torch.float32 and x3 and cin % 16 == 0))
 
-    def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int):
+    @staticmethod
+    def supported_pad1(dtype, cin: int, cout: int) -> bool:
+        """`conv3x3(x, stride=2, padding=1)` (the Blur / DCT slots' down convs) in the same form: f16, 32 or more outputs."""
+        return dtype == torch.float16 and cin % 32 == 0 and cout >= 32 and not _NO_S2D
+
+    def __init__(self, weight_oihw: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, cin: int, pad1: bool = False):
         cout, ctot, kh, kw = weight_oihw.shape
-        assert kh == 3 and kw == 3 and ctot == cin and self.supported(dtype, cin, cout, x3=True)
+        assert kh == 3 and kw == 3 and ctot == cin
+        assert self.supported_pad1(dtype, cin, cout) if pad1 else self.supported(dtype, cin, cout, x3=True)
         self.cin, self.cout, self.device, self.dtype = cin, cout, device, dtype
+        self.pad1 = bool(pad1)   # taps at phase rows y-1, y (pad 1) instead of y, y+1 (pad (0,1,0,1))
         self.code = L.F16 if dtype == torch.float16 else F32X3_CODE
         w = weight_oihw.float()
         w4 = torch.zeros(cout, 4 * cin, 2, 2)
         for dy in range(3):
             for dx in range(3):
-                ry, py, rx, px = dy // 2, dy % 2, dx // 2, dx % 2
+                ry, py, rx, px = ((dy + 1) // 2, (dy + 1) % 2, (dx + 1) // 2, (dx + 1) % 2) if pad1 else (dy // 2, dy % 2, dx // 2, dx % 2)
                 ph = 2 * py + px
                 w4[:, ph * cin:(ph + 1) * cin, ry, rx] = w[:, :, dy, dx]
         d = self._desc(1, 2, 2, pitch_for(cin), pitch_for(cout))
@@ -437,13 +448,15 @@ class PackedDownConv:
         d.cin, d.cin_pitch = 4 * self.cin, cin_pitch
         d.cout, d.cout_pitch = self.cout, cout_pitch
         d.ksize, d.stride, d.subpixel = 2, 1, self.S2D
+        d.pad_before = 1 if self.pad1 else 0
         return d
 
-    def __call__(self, x: Act, want_stats: bool = False) -> Act:
+    def __call__(self, x: Act, want_stats: bool = False, act: int = 0) -> Act:
         if x.c != self.cin or x.h % 2 or x.w % 2 or x.t.dtype != self.dtype:
             raise ValueError(f"downsample conv: expected {self.dtype}, {self.cin} channels and even H, W; got {x.t.dtype}, {x.c}, {x.h}x{x.w}")
         out = new_act(x.n, x.h // 2, x.w // 2, self.cout, x.t.dtype, x.t.device, zero=False)
         d = self._desc(x.n, x.h, x.w, x.pitch, out.pitch)
+        d.act = act
         tiles = lib().elvis_conv_stats_tiles(C.byref(d))
         stats = torch.empty((tiles, self.cout, 2), dtype=torch.float32, device=x.t.device) if want_stats and tiles > 0 else None
         prof = CONV_PROFILER

@@ -26,6 +26,23 @@ def _pc(sd, name, dtype, device, cin, cin2=0):
     return PackedConv(sd[name + ".weight"], sd[name + ".bias"], dtype, device, cin, cin2)
 
 
+class _DownConv:
+    """conv3x3(x, stride=2, padding=1): the space-to-depth form on the halo-tile kernel where it exists (f16, whole
+    32-channel chunks: ops.PackedDownConv with pad1), the generic strided kernel otherwise."""
+
+    def __init__(self, sd, name, dtype, device, cin):
+        w, b = sd[name + ".weight"], sd[name + ".bias"]
+        self.s2d = ops.PackedDownConv(w, b, dtype, device, cin, pad1=True) if ops.PackedDownConv.supported_pad1(dtype, cin, w.shape[0]) else None
+        self.direct = None if self.s2d is not None else PackedConv(w, b, dtype, device, cin)
+
+    def __call__(self, x: Act, act: int = 0) -> Act:
+        if self.s2d is not None and x.h % 2 == 0 and x.w % 2 == 0:
+            return self.s2d(x, act=act)
+        if self.direct is None:
+            raise ValueError("down conv: odd input size for the space-to-depth form")
+        return self.direct(x, stride=2, act=act)
+
+
 class DCNRestorer:
     def __init__(self, cfg: DCNRestorerConfig = DCNRestorerConfig(), state_dict: Optional[Dict] = None,
                  device="cuda:0", dtype=torch.float16, weight_seed: int = 0):
@@ -35,7 +52,7 @@ class DCNRestorer:
         dev = self.device
         with torch.cuda.device(dev):
             self.c1 = _pc(sd, "off.c1", dtype, dev, t)
-            self.d1 = _pc(sd, "off.d1", dtype, dev, oc)
+            self.d1 = _DownConv(sd, "off.d1", dtype, dev, oc)
             self.d2 = _pc(sd, "off.d2", dtype, dev, oc)
             self.u1 = PackedUpConv(sd["off.u1.weight"], sd["off.u1.bias"], dtype, dev, oc)
             self.f = _pc(sd, "off.f", dtype, dev, oc, oc)
@@ -49,7 +66,7 @@ class DCNRestorer:
         """planes [N, H, W, T] in [0,1] -> residual [N, H, W, 1]."""
         cfg = self.cfg
         c1 = self.c1(planes, act=RELU)
-        d1 = self.d1(c1, stride=2, act=RELU)
+        d1 = self.d1(c1, act=RELU)
         d2 = self.d2(d1, act=RELU)
         u1 = self.u1(d2, act=RELU)
         f = self.f(u1, c1, act=RELU)
@@ -130,9 +147,9 @@ class SwinDeblur:
         with torch.cuda.device(dev):
             self.embed = _pc(sd, "embed", dtype, dev, 3)
             self.enc1 = _SwinStage(sd, "enc1", C, cfg.blocks[0], cfg, dtype, dev)
-            self.down1 = _pc(sd, "down1", dtype, dev, C)
+            self.down1 = _DownConv(sd, "down1", dtype, dev, C)
             self.enc2 = _SwinStage(sd, "enc2", 2 * C, cfg.blocks[1], cfg, dtype, dev)
-            self.down2 = _pc(sd, "down2", dtype, dev, 2 * C)
+            self.down2 = _DownConv(sd, "down2", dtype, dev, 2 * C)
             self.mid = _SwinStage(sd, "mid", 4 * C, cfg.blocks[2], cfg, dtype, dev)
             self.up2 = PackedUpConv(sd["up2.weight"], sd["up2.bias"], dtype, dev, 4 * C)
             self.red2 = _pc(sd, "red2", dtype, dev, 2 * C, 2 * C)
@@ -145,8 +162,8 @@ class SwinDeblur:
     def forward(self, img: Act) -> Act:
         """img [N,Hp,Wp,3(8)] in [0,1], Hp,Wp multiples of cfg.align -> restored image (unclamped)."""
         e1 = self.enc1(self.embed(img))
-        e2 = self.enc2(self.down1(e1, stride=2))
-        m = self.mid(self.down2(e2, stride=2))
+        e2 = self.enc2(self.down1(e1))
+        m = self.mid(self.down2(e2))
         d2 = self.dec2(self.red2(self.up2(m), e2))
         d1 = self.dec1(self.red1(self.up1(d2), e1))
         return self.out(d1, residual=img)

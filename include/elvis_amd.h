@@ -150,7 +150,10 @@ typedef struct elvis_conv_desc {
                            C = cin/4 channels, the kernel reads its four (row, column) phases as
                            4C channels of an ho x wo image (ho = h/2, wo = w/2) and applies a 2x2
                            conv whose OIHW weights [cout][4C][2][2] hold W[2ry+py][2rx+px] at input
-                           channel (2py+px)*C + c, tap (ry, rx) (zero where 2r+p > 2).  f16, C % 32 == 0 */
+                           channel (2py+px)*C + c, tap (ry, rx) (zero where 2r+p > 2).  f16, C % 32 == 0.
+                           With pad_before = 1 the same kernel runs "3x3 conv, stride 2, pad 1" (the Blur / DCT
+                           slots' down convs): the 2x2 taps then sit at phase rows y-1, y and hold
+                           W[2ry+py-1][2rx+px-1] (zero where 2r+p < 1).  */
 } elvis_conv_desc;
 #define ELVIS_CONV_S2D 5
 

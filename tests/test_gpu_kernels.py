@@ -393,6 +393,35 @@ def test_downsample_conv_space_to_depth(gpu_device, cfg):
 
 
 @pytest.mark.parametrize("cfg", [
+    # cin, cout, h, w, act   (3x3 / stride 2 / pad 1 in space-to-depth form: the Blur / DCT slots' down convs)
+    (64, 128, 48, 64, 0),
+    (128, 256, 24, 40, 0),       # ragged tile edges
+    (32, 32, 40, 96, 3),         # 32-channel tile, ReLU
+])
+def test_downsample_conv_space_to_depth_pad1(gpu_device, cfg):
+    from elvis_amd import ops
+    cin, cout, h, w, act = cfg
+    g = torch.Generator().manual_seed(23)
+    n = 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    assert ops.PackedDownConv.supported_pad1(torch.float16, cin, cout)
+    conv = ops.PackedDownConv(wt, b, torch.float16, gpu_device, cin, pad1=True)
+    y = conv(_act(x, torch.float16, gpu_device), act=act)
+    ref = F.conv2d(x.half().float(), wt.half().float(), b, stride=2, padding=1)
+    if act == 3:
+        ref = torch.relu(ref)
+    got = _nchw(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL[torch.float16]
+    # and against the generic strided kernel
+    direct = ops.PackedConv(wt, b, torch.float16, gpu_device, cin)
+    y0 = direct(_act(x, torch.float16, gpu_device), stride=2, act=act)
+    assert (_nchw(y0) - got).abs().max().item() < TOL[torch.float16]
+
+
+@pytest.mark.parametrize("cfg", [
     # c1, c2, cout, k, h, w, prologue   (shapes that reach the x3 instantiations: 64- / 128-channel tiles)
     (128, 0, 128, 3, 40, 70, True),
     (96, 32, 64, 3, 33, 65, True),       # two inputs, 64-channel tile
