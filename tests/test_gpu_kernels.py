@@ -693,3 +693,17 @@ def test_conv_weight_stationary(gpu_device, cfg):
     finally:
         check(lib().elvis_conv_debug_set(b"no_halo", -1))
     assert (_nchw(y0) - got).abs().max().item() < TOL[dtype]
+
+
+def test_conv_weight_stationary_odd_tile_count(gpu_device):
+    """One image of 33 x 17 = 561 tiles: the last tile pair has only its first half (conv_ws.inc: `t < ntiles`)."""
+    from elvis_amd import ops
+    g = torch.Generator().manual_seed(32)
+    cin, cout, h, w = 32, 64, 264, 544
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = ops.PackedConv(wt, b, torch.float16, gpu_device, cin)
+    y = conv(_act(x, torch.float16, gpu_device), act=3)
+    ref = torch.relu(F.conv2d(x.half().float(), wt.half().float(), b, padding=1))
+    assert (_nchw(y) - ref).abs().max().item() < TOL[torch.float16]
